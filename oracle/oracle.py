@@ -1,0 +1,204 @@
+"""ctypes binding of the CPU oracle (oracle/sm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (stereomatch_amd) never imports it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libsm_oracle.so")
+
+
+class Params(C.Structure):
+    """Mirror of `smo_params` (sm_oracle.h); defaults = StereoParameters.cpp:33-116."""
+
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("n_bands", C.c_int),
+        ("disp_min", C.c_int), ("disp_num", C.c_int), ("disp_den", C.c_int),
+        ("disp_n", C.c_int), ("frame_diff_sign", C.c_int),
+        ("match_fn", C.c_int), ("match_interp", C.c_int), ("match_max", C.c_int),
+        ("match_interval", C.c_int), ("match_interpolated", C.c_int),
+        ("aggr_fn", C.c_int), ("aggr_window_size", C.c_int), ("aggr_iter", C.c_int),
+        ("aggr_minfilter", C.c_int),
+        ("diff_lambda", C.c_float), ("diff_beta", C.c_float),
+        ("opt_smoothness", C.c_float), ("opt_grad_thresh", C.c_float),
+        ("opt_grad_penalty", C.c_float),
+        ("disp_step", C.c_float), ("disp_scale", C.c_float),
+    ]
+
+
+def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
+                frame_ref=0, frame_match=1, disp_scale=1.0, **kw):
+    """Defaults of ReInitializeAlgParams (StereoParameters.cpp:55-116) and the
+    derivation of num/den/disp_n of ComputeCorrespondence (StereoMatcher.cpp:60-82)."""
+    def rnd(x):
+        return int(x + 0.5) if x >= 0 else int(x - 0.5)
+    num = 1 if disp_step < 1.0 else rnd(disp_step)
+    den = rnd(1.0 / disp_step) if disp_step < 1.0 else 1
+    step = np.float32(num) / np.float32(den)
+    inv = np.float32(den) / np.float32(num)
+    disp_n = int(np.float32(inv * np.float32(disp_max - disp_min))) + 1
+    p = Params(
+        width=width, height=height, n_bands=n_bands,
+        disp_min=disp_min, disp_num=num, disp_den=den, disp_n=disp_n,
+        frame_diff_sign=1 if frame_match - frame_ref > 0 else -1,
+        match_fn=1, match_interp=3, match_max=1000, match_interval=0, match_interpolated=0,
+        aggr_fn=1, aggr_window_size=7, aggr_iter=1, aggr_minfilter=0,
+        diff_lambda=0.15, diff_beta=0.5,
+        opt_smoothness=1.0, opt_grad_thresh=5.0, opt_grad_penalty=1.0,
+        disp_step=float(step), disp_scale=disp_scale,
+    )
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("sm_oracle.c", "sm_oracle.h", "Makefile")]
+    if force or not os.path.exists(_SO) or any(
+            os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        fp = C.POINTER(C.c_float)
+        u8 = C.POINTER(C.c_uint8)
+        i32 = C.POINTER(C.c_int32)
+        pp = C.POINTER(Params)
+        L.smo_match_outside.restype = C.c_float
+        L.smo_match_outside.argtypes = [pp]
+        L.smo_raw_costs.argtypes = [u8, u8, C.c_long, pp, fp, C.c_long]
+        L.smo_box_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int]
+        L.smo_min_filter.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int]
+        L.smo_convolve_14641.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_long]
+        L.smo_diffusion_iter.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_long,
+                                         C.c_float, C.c_float]
+        L.smo_pad_costs.argtypes = [fp, C.c_long, pp]
+        L.smo_wta.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_long, i32, fp]
+        L.smo_aggregate.argtypes = [fp, C.c_long, pp]
+        L.smo_final_energy.restype = C.c_float
+        L.smo_final_energy.argtypes = [fp, C.c_long, i32, u8, C.c_long, pp]
+        L.smo_depth_image.argtypes = [i32, C.c_int, pp, u8]
+        L.smo_compute_correspondence.restype = C.c_float
+        L.smo_compute_correspondence.argtypes = [u8, u8, C.c_long, pp, i32, fp, u8]
+        for name in ("smo_raw_costs", "smo_box_filter", "smo_min_filter", "smo_convolve_14641",
+                     "smo_diffusion_iter", "smo_pad_costs", "smo_wta", "smo_aggregate",
+                     "smo_depth_image"):
+            getattr(L, name).restype = None
+        _lib = L
+    return _lib
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u8(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def _i32(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _img(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    return a
+
+
+def match_outside(p):
+    return float(lib().smo_match_outside(C.byref(p)))
+
+
+def raw_costs(ref, mtc, p):
+    ref, mtc = _img(ref), _img(mtc)
+    h, w, b = ref.shape
+    assert (w, h, b) == (p.width, p.height, p.n_bands) and mtc.shape == ref.shape
+    cost = np.empty((h, w, p.disp_n), np.float32)
+    lib().smo_raw_costs(_u8(ref), _u8(mtc), w * b, C.byref(p), _fp(cost), w * p.disp_n)
+    return cost
+
+
+def _inplace(cost):
+    cost = np.array(cost, dtype=np.float32, order="C", copy=True)
+    h, w, d = cost.shape
+    return cost, np.empty_like(cost), h, w, d
+
+
+def box_filter(cost, window, average=True):
+    c, t, h, w, d = _inplace(cost)
+    lib().smo_box_filter(_fp(c), _fp(t), w, h, d, w * d, window, int(average))
+    return c
+
+
+def min_filter(cost, window):
+    c, t, h, w, d = _inplace(cost)
+    lib().smo_min_filter(_fp(c), _fp(t), w, h, d, w * d, window)
+    return c
+
+
+def convolve_14641(cost):
+    c, t, h, w, d = _inplace(cost)
+    lib().smo_convolve_14641(_fp(c), _fp(t), w, h, d, w * d)
+    return c
+
+
+def diffusion_iter(cost, lam, beta=0.0, cost0=None):
+    src = np.ascontiguousarray(cost, np.float32)
+    h, w, d = src.shape
+    dst = np.empty_like(src)
+    c0 = np.ascontiguousarray(cost0, np.float32) if cost0 is not None else None
+    lib().smo_diffusion_iter(_fp(src), _fp(dst), _fp(c0) if c0 is not None else None,
+                             w, h, d, w * d, lam, beta)
+    return dst
+
+
+def pad_costs(cost, p):
+    c = np.array(cost, dtype=np.float32, order="C", copy=True)
+    lib().smo_pad_costs(_fp(c), p.width * p.disp_n, C.byref(p))
+    return c
+
+
+def wta(cost):
+    c = np.ascontiguousarray(cost, np.float32)
+    h, w, d = c.shape
+    disp = np.empty((h, w), np.int32)
+    best = np.empty((h, w), np.float32)
+    lib().smo_wta(_fp(c), w, h, d, w * d, _i32(disp), _fp(best))
+    return disp, best
+
+
+def aggregate(cost, p):
+    c = np.array(cost, dtype=np.float32, order="C", copy=True)
+    lib().smo_aggregate(_fp(c), p.width * p.disp_n, C.byref(p))
+    return c
+
+
+def compute_correspondence(ref, mtc, p):
+    """Returns (disparity int32 [H,W], best_cost f32 [H,W], depth u8 [H,W], final_energy)."""
+    ref, mtc = _img(ref), _img(mtc)
+    h, w, b = ref.shape
+    assert (w, h, b) == (p.width, p.height, p.n_bands) and mtc.shape == ref.shape
+    disp = np.empty((h, w), np.int32)
+    best = np.empty((h, w), np.float32)
+    depth = np.empty((h, w), np.uint8)
+    e = lib().smo_compute_correspondence(_u8(ref), _u8(mtc), w * b, C.byref(p),
+                                         _i32(disp), _fp(best), _u8(depth))
+    return disp, best, depth, float(e)

@@ -1,0 +1,511 @@
+/*
+ * sm_oracle.c -- CPU restatement of the StereoMatch cost-volume front end.
+ *
+ * TEST INFRASTRUCTURE ONLY (see sm_oracle.h).  Plain C99; build with
+ *   gcc -O2 -ffp-contract=off -fPIC -shared
+ * (no -march=native, no -ffast-math: binary32 arithmetic in source order, the
+ * semantics of the reference's `g++ -O2` x86-64 build, Makefile:1).
+ *
+ * Written from the reference's documented behaviour; citations give the
+ * reference lines whose arithmetic each block follows.
+ */
+#include "sm_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline int imin(int a, int b) { return a < b ? a : b; }
+static inline int imax(int a, int b) { return a > b ? a : b; }
+static inline int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+/* ------------------------------------------------------------------------- */
+/* raw costs                                                                  */
+
+static int cutoff_of(const smo_params *p)
+{
+    /* StcRawCosts.cpp:144, :366 */
+    return p->match_fn == SMO_SD ? p->match_max * p->match_max : abs(p->match_max);
+}
+
+float smo_match_outside(const smo_params *p)
+{
+    /* StcRawCosts.cpp:365-367: worst per-pixel cost over all bands, trimmed to the cutoff */
+    int worst = p->n_bands * (p->match_fn == SMO_SD ? 255 * 255 : 255);
+    return (float)imin(worst, cutoff_of(p));
+}
+
+/* Warp1D.cpp:130-142 */
+static float cubic_interp(float x0, float v0, float v1, float v2, float v3)
+{
+    float x1 = 1.0f - x0;
+    float s0 = v2 - v0;
+    float s1 = v1 - v3;
+    float d1 = v2 - v1;
+    float phi0 = d1 * (x0 * x0) * (2.0f * x1 + 1.0f);
+    float phi1a = s0 * x0 * (x1 * x1);
+    float phi1b = s1 * x1 * (x0 * x0);
+    return v1 + phi0 + phi1a + phi1b;
+}
+
+/* StcRawCosts.cpp:67-105: fill the s-1 samples between original pixels (spacing s) */
+static void interpolate_line(int *buf, int s, int w, int nb, int interp)
+{
+    float si = 1.0f / s;
+    for (int x = 0; x < w - 1; x++) {
+        for (int b = 0; b < nb; b++) {
+            int *v = &buf[s * x * nb + b];
+            float i0 = (float)v[0];
+            float i1 = (float)v[s * nb];
+            if (interp == SMO_CUBIC) {
+                float im = (x > 0) ? (float)v[-s * nb] : (i0 - (i1 - i0));
+                float ip = (x + 1 < w - 1) ? (float)v[2 * s * nb] : (i1 + (i1 - i0));
+                float sf = si;
+                for (int is = 1; is < s; is++, sf += si) {
+                    v += nb;
+                    v[0] = (int)cubic_interp(sf, im, i0, i1, ip);
+                }
+            } else {
+                float d = (i1 - i0) / (float)s;
+                for (int is = 1; is < s; is++) {
+                    v += nb;
+                    i0 += d;
+                    v[0] = (int)i0;
+                }
+            }
+        }
+    }
+}
+
+/* StcRawCosts.cpp:107-128: Birchfield-Tomasi half-sample min / max per band */
+static void bt_min_max(const int *line, int *mn, int *mx, int n, int nb)
+{
+    for (int k = 0; k < nb; k++) {
+        int half_r = line[k];   /* h[-1] = v[0] */
+        int next = line[k];
+        for (int x = 0, l = k; x < n; x++, l += nb) {
+            int half_l = half_r;
+            int cur = next;
+            if (x < n - 1)
+                next = line[l + nb];
+            half_r = (cur + next + 1) / 2;
+            mn[l] = imin(half_l, imin(cur, half_r));
+            mx[l] = imax(half_l, imax(cur, half_r));
+        }
+    }
+}
+
+/* StcRawCosts.cpp:130-218.  rmx/mmx NULL => plain difference. */
+static void match_line(int w, int nb, int interpolated, const int *rmn, const int *rmx,
+                       const int *mmn, const int *mmx, float *cost, float *cost1,
+                       int disp_n, int disp, int den, int match_fn, int match_max,
+                       float match_outside)
+{
+    int n = (w - 1) * den + 1;
+    int s = interpolated ? 1 : den;
+    int cutoff = match_fn == SMO_SD ? match_max * match_max : abs(match_max);
+    const float bad = -1.0f;
+
+    for (int x = 0; x < n; x += s) {
+        cost1[x] = bad;
+        int xm = x + disp;
+        if (xm < 0 || xm >= n)
+            continue;
+        const int *rn = &rmn[x * nb];
+        const int *mn = &mmn[xm * nb];
+        int sum = 0;
+        for (int ib = 0; ib < nb; ib++) {
+            int d1 = mn[ib] - rn[ib];
+            if (rmx && mmx) {
+                /* :168-180: distance between the intervals [rn,rx] and [mn,mx] */
+                int rxv = rmx[x * nb + ib], mxv = mmx[xm * nb + ib];
+                int lo = imax(rn[ib], mn[ib]);
+                int hi = imin(rxv, mxv);
+                if (lo <= hi)
+                    d1 = 0;
+                else
+                    d1 = (mn[ib] > rxv) ? mn[ib] - rxv : rn[ib] - mxv;
+            }
+            sum += (match_fn == SMO_SD) ? d1 * d1 : abs(d1);
+        }
+        cost1[x] = (float)imin(sum, cutoff);
+    }
+
+    /* :193-198 with UNDEFINED_COST = true (CudaRawCosts.h:23) */
+    for (int x = 0; x < n && cost1[x] == bad; x += s)
+        cost1[x] = match_outside;
+    for (int x = n - 1; x >= 0 && cost1[x] == bad; x -= s)
+        cost1[x] = match_outside;
+
+    /* :200-217 */
+    int dh = den / 2;
+    float box_scale = (float)(1.0 / (2 * dh + 1));
+    for (int x = 0, i = 0; i < w; x += den, i++) {
+        if (interpolated && den > 1) {
+            float acc = 0;
+            for (int k = -dh; k <= dh; k++)
+                acc += cost1[clampi(x + k, n)];
+            cost[(long)i * disp_n] = (float)(int)((double)(box_scale * acc) + 0.5);
+        } else {
+            cost[(long)i * disp_n] = cost1[x];
+        }
+    }
+}
+
+void smo_raw_costs(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
+                   const smo_params *p, float *cost, long row_elems)
+{
+    int w = p->width, h = p->height, nb = p->n_bands, den = p->disp_den;
+    int n = den * (w - 1) + 1;                       /* :355 */
+    int interval = p->match_interval ? 1 : 0;        /* :354 */
+    float outside = smo_match_outside(p);
+    size_t len = (size_t)n * nb;
+    int *buf0 = calloc(len * 6, sizeof(int));
+    int *buf1 = buf0 + len, *min0 = buf1 + len, *max0 = min0 + len;
+    int *min1 = max0 + len, *max1 = min1 + len;
+    float *cost1 = calloc((size_t)n, sizeof(float));
+
+    for (int y = 0; y < h; y++) {
+        const uint8_t *r = ref + (size_t)y * img_row_bytes;
+        const uint8_t *m = mtc + (size_t)y * img_row_bytes;
+        for (int x = 0; x < w; x++)                  /* :383-390 */
+            for (int k = 0; k < nb; k++) {
+                buf0[(size_t)x * den * nb + k] = r[x * nb + k];
+                buf1[(size_t)x * den * nb + k] = m[x * nb + k];
+            }
+        if (den > 1) {                               /* :393-397 */
+            interpolate_line(buf1, den, w, nb, p->match_interp);
+            interpolate_line(buf0, den, w, nb, p->match_interp);
+        }
+        if (interval) {                              /* :398-402 */
+            bt_min_max(buf1, min1, max1, n, nb);
+            if (p->match_interpolated)
+                bt_min_max(buf0, min0, max0, n, nb);
+        }
+        for (int k = 0; k < p->disp_n; k++) {        /* :405-416 */
+            int disp = -p->frame_diff_sign * (den * p->disp_min + k * p->disp_num);
+            const int *rmn = interval ? (p->match_interpolated ? min0 : buf0) : buf0;
+            const int *rmx = interval ? (p->match_interpolated ? max0 : buf0) : NULL;
+            const int *mmn = interval ? min1 : buf1;
+            const int *mmx = interval ? max1 : NULL;
+            match_line(w, nb, p->match_interpolated, rmn, rmx, mmn, mmx,
+                       cost + (size_t)y * row_elems + k, cost1, p->disp_n, disp, den,
+                       p->match_fn, p->match_max, outside);
+        }
+    }
+    free(cost1);
+    free(buf0);
+}
+
+/* StcRawCosts.cpp:437-476 */
+void smo_pad_costs(float *cost, long row_elems, const smo_params *p)
+{
+    int w = p->width, den = p->disp_den;
+    int n = (w - 1) * den + 1;
+    float outside = smo_match_outside(p);
+    for (int y = 0; y < p->height; y++)
+        for (int k = 0; k < p->disp_n; k++) {
+            int disp = -p->frame_diff_sign * (den * p->disp_min + k * p->disp_num);
+            disp -= den - 1;                         /* :448 */
+            float *c = cost + (size_t)y * row_elems + k;
+            for (int x = disp, i = 0; x < n + disp; x += den, i++)
+                if (x < 0 || x >= n)
+                    c[(long)i * p->disp_n] = outside;
+        }
+}
+
+/* ------------------------------------------------------------------------- */
+/* box filter                                                                 */
+
+/* BoxFilter.cpp:70-170: n_sums running sums along lines of length len, element
+ * spacing `stride`; replicate border (borderIndex :29-65, eBorderReplicate). */
+static void box_lines(const float *src, float *dst, long n_sums, int len, long stride,
+                      int w, int average)
+{
+    int pr = w / 2, pl = pr - w;                     /* :209-210 */
+    float scale = (float)(average ? 1.0 / w : 1);    /* :89 */
+
+    for (long k = 0; k < n_sums; k++) {              /* :92-107 */
+        float acc = 0;
+        for (int i = pl + 1; i <= pr; i++)
+            acc += scale * src[k + stride * clampi(i, len)];
+        dst[k] = acc;
+    }
+    for (int x = 1; x < len; x++) {                  /* :117-168 */
+        const float *lft = src + stride * clampi(x + pl, len);
+        const float *rgt = src + stride * clampi(x + pr, len);
+        const float *prev = dst + stride * (x - 1);
+        float *cur = dst + stride * x;
+        for (long k = 0; k < n_sums; k++)
+            cur[k] = prev[k] + scale * (-lft[k] + rgt[k]);
+    }
+}
+
+void smo_box_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,
+                    int window, int average)
+{
+    for (int y = 0; y < h; y++)                      /* :214-220 */
+        box_lines(cost + (size_t)y * row_elems, tmp + (size_t)y * row_elems, nb, w, nb,
+                  window, average);
+    box_lines(tmp, cost, (long)nb * w, h, row_elems, window, average);   /* :225-232 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* min filter                                                                 */
+
+/* MinFilter.cpp:29-82 computes, for every x, min over buf[x+pl+1 .. x+pr] of the
+ * replicate-padded line (its incremental update is an optimisation of exactly that,
+ * cf. the slow form :85-120).  min is order independent, so the direct form is exact. */
+static void min_lines(const float *src, float *dst, long n_lines, int len, long stride,
+                      int w)
+{
+    int pr = w / 2, pl = pr - w;                     /* :139-140 */
+    for (int x = 0; x < len; x++) {
+        float *o = dst + stride * x;
+        const float *first = src + stride * clampi(x + pl + 1, len);
+        for (long k = 0; k < n_lines; k++)
+            o[k] = first[k];
+        for (int i = x + pl + 2; i <= x + pr; i++) {
+            const float *s = src + stride * clampi(i, len);
+            for (long k = 0; k < n_lines; k++)
+                if (s[k] < o[k])
+                    o[k] = s[k];
+        }
+    }
+}
+
+void smo_min_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,
+                    int window)
+{
+    for (int y = 0; y < h; y++)                      /* rows, :156-170 */
+        min_lines(cost + (size_t)y * row_elems, tmp + (size_t)y * row_elems, nb, w, nb,
+                  window);
+    min_lines(tmp, cost, (long)nb * w, h, row_elems, window);   /* columns, :183-201 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* separable binomial                                                         */
+
+static const float k14641[5] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};  /* Convolve.cpp:290 */
+
+void smo_convolve_14641(float *cost, float *tmp, int w, int h, int nb, long row_elems)
+{
+    /* horizontal, Convolve.cpp:224 via :86-111 with TrimIndex replicate (:42-43) */
+    for (int y = 0; y < h; y++) {
+        const float *s = cost + (size_t)y * row_elems;
+        float *t = tmp + (size_t)y * row_elems;
+        for (int x = 0; x < w; x++) {
+            const float *t0 = s + (long)nb * clampi(x - 2, w);
+            const float *t1 = s + (long)nb * clampi(x - 1, w);
+            const float *t2 = s + (long)nb * x;
+            const float *t3 = s + (long)nb * clampi(x + 1, w);
+            const float *t4 = s + (long)nb * clampi(x + 2, w);
+            for (int d = 0; d < nb; d++) {
+                float acc = 0.0f;
+                acc += k14641[0] * t0[d];
+                acc += k14641[1] * t1[d];
+                acc += k14641[2] * t2[d];
+                acc += k14641[3] * t3[d];
+                acc += k14641[4] * t4[d];
+                t[(long)nb * x + d] = acc;
+            }
+        }
+    }
+    /* vertical, Convolve.cpp:225, top row first; result back into cost (:237-249) */
+    for (int y = 0; y < h; y++) {
+        const float *r0 = tmp + (size_t)clampi(y - 2, h) * row_elems;
+        const float *r1 = tmp + (size_t)clampi(y - 1, h) * row_elems;
+        const float *r2 = tmp + (size_t)y * row_elems;
+        const float *r3 = tmp + (size_t)clampi(y + 1, h) * row_elems;
+        const float *r4 = tmp + (size_t)clampi(y + 2, h) * row_elems;
+        float *o = cost + (size_t)y * row_elems;
+        for (long i = 0; i < (long)nb * w; i++) {
+            float acc = 0.0f;
+            acc += k14641[0] * r0[i];
+            acc += k14641[1] * r1[i];
+            acc += k14641[2] * r2[i];
+            acc += k14641[3] * r3[i];
+            acc += k14641[4] * r4[i];
+            o[i] = acc;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* diffusion / membrane                                                       */
+
+void smo_diffusion_iter(const float *src, float *dst, const float *cost0,
+                        int w, int h, int nb, long row_elems, float lambda, float beta)
+{
+    /* StcDiffusion.cpp:84-99, :112-118: a missing neighbour is replaced by the centre
+     * value in that neighbour's slot; sum order ((l + r) + u) + d. */
+    float a = 1 - lambda * (beta + 4);
+    long dx = nb;
+    for (int y = 0; y < h; y++) {
+        const float *s = src + (size_t)y * row_elems;
+        float *o = dst + (size_t)y * row_elems;
+        long up = (y > 0) ? -row_elems : 0;
+        long dn = (y < h - 1) ? row_elems : 0;
+        for (long i = 0; i < dx * w; i++) {
+            long lf = (i - dx >= 0) ? -dx : 0;
+            long rt = (i + dx < dx * w) ? dx : 0;
+            o[i] = a * s[i] + lambda * (s[i + lf] + s[i + rt] + s[i + up] + s[i + dn]);
+        }
+    }
+    if (beta > 0.0f) {                               /* :122-136 */
+        float lb = lambda * beta;
+        for (int y = 0; y < h; y++) {
+            const float *c0 = cost0 + (size_t)y * row_elems;
+            float *o = dst + (size_t)y * row_elems;
+            for (long i = 0; i < dx * w; i++)
+                o[i] += lb * c0[i];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* WTA, aggregation dispatch, energy, depth image                             */
+
+void smo_wta(const float *cost, int w, int h, int nb, long row_elems,
+             int32_t *disp, float *best_cost)
+{
+    for (int y = 0; y < h; y++) {
+        const float *c = cost + (size_t)y * row_elems;
+        for (int x = 0; x < w; x++, c += nb) {
+            int best = 0;
+            float bc = c[0];
+            for (int d = 1; d < nb; d++)
+                if (c[d] < bc) {                     /* strict: lowest d wins ties, :47 */
+                    bc = c[d];
+                    best = d;
+                }
+            if (disp)
+                disp[(size_t)y * w + x] = best;
+            if (best_cost)
+                best_cost[(size_t)y * w + x] = bc;
+        }
+    }
+}
+
+void smo_aggregate(float *cost, long row_elems, const smo_params *p)
+{
+    int w = p->width, h = p->height, nb = p->disp_n;
+    size_t bytes = (size_t)row_elems * h * sizeof(float);
+    float *tmp = malloc(bytes);
+    float *cost0 = NULL;
+    float beta = p->diff_beta;
+
+    if (p->aggr_fn == SMO_MEMBRANE && beta > 0.0f && p->aggr_iter > 0) {
+        cost0 = malloc(bytes);                       /* StcAggregate.cpp:262, StcDiffusion.cpp:52-56 */
+        memcpy(cost0, cost, bytes);
+    }
+    for (int iter = 0; iter < p->aggr_iter; iter++) {
+        switch (p->aggr_fn) {
+        case SMO_BOX:                                /* StcAggregate.cpp:54-58 */
+            smo_box_filter(cost, tmp, w, h, nb, row_elems, p->aggr_window_size, 1);
+            break;
+        case SMO_BINOMIAL:                           /* :287-288 */
+            smo_convolve_14641(cost, tmp, w, h, nb, row_elems);
+            break;
+        case SMO_DIFFUSION:                          /* :305-306: beta forced to 0 */
+            memcpy(tmp, cost, bytes);
+            smo_diffusion_iter(tmp, cost, NULL, w, h, nb, row_elems, p->diff_lambda, 0.0f);
+            break;
+        case SMO_MEMBRANE:                           /* :317 */
+            memcpy(tmp, cost, bytes);
+            smo_diffusion_iter(tmp, cost, cost0, w, h, nb, row_elems, p->diff_lambda, beta);
+            break;
+        default:
+            break;
+        }
+    }
+    if (p->aggr_minfilter > 1)                       /* :351-360 */
+        smo_min_filter(cost, tmp, w, h, nb, row_elems, p->aggr_minfilter);
+    smo_pad_costs(cost, row_elems, p);               /* :365 */
+    free(cost0);
+    free(tmp);
+}
+
+/* StcOptimize.cpp:61-82 */
+static float ncost(const uint8_t *a, const uint8_t *b, int nb, const smo_params *p)
+{
+    float d2 = 0.0f;
+    for (int k = 0; k < nb; k++) {
+        float d = (float)((int)a[k] - (int)b[k]);
+        d2 += d * d;
+    }
+    d2 /= (float)(nb - (nb > 1));
+    float da = (float)sqrt((double)d2);
+    float s = p->opt_smoothness;
+    if (da < p->opt_grad_thresh)
+        s *= p->opt_grad_penalty;
+    return s;
+}
+
+float smo_final_energy(const float *cost, long row_elems, const int32_t *disp,
+                       const uint8_t *ref, long img_row_bytes, const smo_params *p)
+{
+    /* StcGraphCut.cpp:46-70 with the smoothness weights of StcOptimize.cpp:103-116 */
+    int w = p->width, h = p->height, nb = p->n_bands, nd = p->disp_n;
+    float dsum = 0.0f, nsum = 0.0f;
+    for (int y = 0; y < h; y++) {
+        const int32_t *cur = disp + (size_t)y * w;
+        const int32_t *nxt = disp + (size_t)(y + (y < h - 1)) * w;
+        const uint8_t *i0 = ref + (size_t)y * img_row_bytes;
+        const uint8_t *i1 = ref + (size_t)(y + (y < h - 1)) * img_row_bytes;
+        const float *dc = cost + (size_t)y * row_elems;
+        for (int x = 0; x < w; x++, dc += nd) {
+            int d = cur[x];
+            dsum += dc[d];
+            if (y < h - 1 && d != nxt[x])
+                nsum += ncost(i0 + x * nb, i1 + x * nb, nb, p);
+            if (x < w - 1 && d != cur[x + 1])
+                nsum += ncost(i0 + x * nb, i0 + (x + 1) * nb, nb, p);
+        }
+    }
+    return dsum + nsum;
+}
+
+void smo_depth_image(const int32_t *disp, int n, const smo_params *p, uint8_t *depth)
+{
+    float d_offset = (float)p->disp_min;
+    float offset = (float)(-p->disp_min * p->disp_scale + 0.5);   /* StereoMatcher.cpp:177 */
+    for (int i = 0; i < n; i++) {
+        /* StcRefine.cpp:37-38 via Convert.cpp:31-40 (int -> float, no clip) */
+        float fd;
+        if (p->disp_step != 1.0f || d_offset != 0.0f)
+            fd = (float)disp[i] * p->disp_step + d_offset;
+        else
+            fd = (float)disp[i];
+        /* float -> uchar: scale/offset, clip to [0,255], truncate (Convert.cpp:33-40) */
+        float v;
+        if (p->disp_scale != 1.0f || offset != 0.0f)
+            v = fd * p->disp_scale + offset;
+        else
+            v = fd;
+        v = v < 0.0f ? 0.0f : v;
+        v = v > 255.0f ? 255.0f : v;
+        depth[i] = (uint8_t)v;
+    }
+}
+
+float smo_compute_correspondence(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
+                                 const smo_params *p, int32_t *disp, float *best_cost,
+                                 uint8_t *depth)
+{
+    int w = p->width, h = p->height;
+    long row_elems = (long)w * p->disp_n;
+    float *cost = malloc((size_t)row_elems * h * sizeof(float));
+    int32_t *d = disp ? disp : malloc((size_t)w * h * sizeof(int32_t));
+
+    smo_raw_costs(ref, mtc, img_row_bytes, p, cost, row_elems);
+    smo_aggregate(cost, row_elems, p);
+    smo_wta(cost, w, h, p->disp_n, row_elems, d, best_cost);
+    float energy = smo_final_energy(cost, row_elems, d, ref, img_row_bytes, p);
+    if (depth)
+        smo_depth_image(d, w * h, p, depth);
+    if (!disp)
+        free(d);
+    free(cost);
+    return energy;
+}
