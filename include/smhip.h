@@ -1,0 +1,147 @@
+/*
+ * smhip.h -- C-ABI of the MI355X (gfx950) cost-volume front end of StereoMatch.
+ *
+ * This is the drop-in boundary: the functions below are what the reference's device
+ * layer (CudaRawCosts.h, CudaBoxFilter.h, CudaConvolve.h, CudaUtilities.h) would bind
+ * to.  Plain C, pointers and sizes only.  All `d_*` pointers are DEVICE pointers
+ * (from smhip_malloc, or any hipMalloc'd / torch-allocated buffer on the context's
+ * device).  Every call is enqueued on the context's stream (default: the null stream);
+ * calls return after enqueueing -- use smhip_sync() before reading results through
+ * anything other than smhip_memcpy_d2h*() (which synchronise themselves).
+ *
+ * Return value: SMHIP_OK (0) or a negative error code; smhip_last_error() returns a
+ * message for the last failing call of the calling thread.  Host misuse that the
+ * reference reports with `throw CError(...)` (e.g. BoxFilter.cpp:179-180) comes back
+ * as SMHIP_EINVAL; HIP runtime failures (reference: GPUERRORCHECK -> exit(1),
+ * CudaUtilities.h:32-40) come back as SMHIP_EHIP and never terminate the process.
+ *
+ * Threading: like the reference (single host thread) a context is not
+ * thread-safe; use one context per host thread.
+ *
+ * Data layout (Image.h:160-164): images are uint8 [H][W][n_bands] with a row pitch in
+ * bytes; the disparity-space image (DSI) is float [H][W][D], D innermost, row stride
+ * `row_elems` floats (>= W*D; the reference's CImage rounds rows up to 8 bytes,
+ * Image.cpp:97-98).  All float arithmetic follows the reference CPU path's operation
+ * order with no FMA contraction, so results are bit-identical to it.
+ */
+#ifndef SMHIP_H
+#define SMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMHIP_OK        0
+#define SMHIP_EINVAL   (-1)   /* bad argument / unsupported parameter combination */
+#define SMHIP_EHIP     (-2)   /* HIP runtime error */
+#define SMHIP_ENOMEM   (-3)   /* device allocation failed */
+
+typedef struct smhip_ctx smhip_ctx;
+
+/* Replaces LineProcessStruct (CudaRawCosts.h:97-114): the parameters RawCosts derives
+ * in ComputeCorrespondence (StereoMatcher.cpp:60-82) and StcRawCosts.cpp:354-367. */
+typedef struct smhip_match_params {
+    int width, height, n_bands;         /* image shape; n_bands 1 or 4 (StereoIO.cpp:76-81) */
+    int disp_min;                       /* smallest disparity */
+    int disp_num, disp_den;             /* disparity step = num/den */
+    int disp_n;                         /* number of disparity levels D */
+    int frame_diff_sign;                /* +1 / -1 (StereoMatcher.cpp:60-61) */
+    int match_fn;                       /* 1 = AD, 2 = SD (EStereoMatchFn) */
+    int match_interp;                   /* 1 = linear, 3 = cubic (EStereoInterpFn) */
+    int match_max;                      /* truncation */
+    int match_interval;                 /* Birchfield-Tomasi */
+    int match_interpolated;             /* intervals on the reference line too */
+} smhip_match_params;
+
+/* ---- context (replaces prepareDevice, CudaUtilities.h:90-91 / .cu:93-127) ---- */
+int smhip_init(int device, smhip_ctx **ctx);
+int smhip_shutdown(smhip_ctx *ctx);
+const char *smhip_last_error(void);
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
+int smhip_set_stream(smhip_ctx *ctx, void *hip_stream);
+int smhip_sync(smhip_ctx *ctx);
+/* bytes of device workspace the context currently holds (temporaries of the filters) */
+size_t smhip_workspace_bytes(const smhip_ctx *ctx);
+
+/* ---- memory (replaces Allocate/Copy/FreeGPUMemory, CudaUtilities.cu:49-77) ---- */
+int smhip_malloc(smhip_ctx *ctx, size_t bytes, void **d_ptr);
+int smhip_free(smhip_ctx *ctx, void *d_ptr);
+int smhip_memcpy_h2d(smhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int smhip_memcpy_d2h(smhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* device-to-device on the context's stream (CopyPixels(m_cost, m_cost0), StcAggregate.cpp:262) */
+int smhip_memcpy_d2d(smhip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* pitched copies, for hosts whose rows are padded (Image.cpp:97-98) */
+int smhip_memcpy2d_h2d(smhip_ctx *ctx, void *d_dst, size_t d_pitch, const void *h_src,
+                       size_t h_pitch, size_t width_bytes, size_t rows);
+int smhip_memcpy2d_d2h(smhip_ctx *ctx, void *h_dst, size_t h_pitch, const void *d_src,
+                       size_t d_pitch, size_t width_bytes, size_t rows);
+
+/* ---- stage operators ---- */
+
+/* m_match_outside (StcRawCosts.cpp:365-367) */
+float smhip_match_outside(const smhip_match_params *p);
+
+/* Replaces LineProcess (CudaRawCosts.h:145, called from RawCostsGPU StcRawCosts.cpp:305);
+ * arithmetic of RawCostsCPU/MatchLine/BirchfieldTomasiMinMax/InterpolateLine
+ * (StcRawCosts.cpp:67-218, 327-435). */
+int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                    size_t img_pitch, const smhip_match_params *p,
+                    float *d_cost, size_t row_elems);
+
+/* Replaces CudaBoxFilterXY (CudaBoxFilter.h:31-32, called from BoxFilter.cpp:197) with the
+ * semantics of the CPU BoxFilter<float> (BoxFilter.cpp:173-239): any window, running sum,
+ * replicate border, in place.  x_width != y_width is rejected like BoxFilter.cpp:179-180. */
+int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
+                     size_t row_elems, int x_width, int y_width, int average);
+
+/* MinFilter<float> (MinFilter.h:31, MinFilter.cpp:122-209), replicate border, in place */
+int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
+                     size_t row_elems, int x_width, int y_width);
+
+/* Replaces CudaConvolveXY(..., BINOMIAL14641) (CudaConvolve.h:57-58, Convolve.cpp:214-215)
+ * with the semantics of the CPU ConvolveSeparable (Convolve.cpp:166-254): kernel 14641 in
+ * x then y, replicate border, scale 1, offset 0, in place. */
+int smhip_convolve_14641(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
+                         size_t row_elems);
+
+/* One AggrDiffusion iteration (StcDiffusion.cpp:28-137) d_src -> d_dst (distinct buffers);
+ * d_cost0 (the un-aggregated DSI) is read only when beta > 0 (membrane model). */
+int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst,
+                         const float *d_cost0, int w, int h, int n_bands,
+                         size_t row_elems, float lambda, float beta);
+
+/* PadCosts (StcRawCosts.cpp:437-476) */
+int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems,
+                    const smhip_match_params *p);
+
+/* OptWTA (StcOptimize.cpp:26-56); d_best (may be NULL) receives m_cost at the winner, which
+ * Optimize needs for final_energy (StcOptimize.cpp:270-278). */
+int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
+              size_t row_elems, int32_t *d_disp, float *d_best);
+
+/* ---- fused path: RawCosts -> AggrBox (1 iteration) -> PadCosts -> OptWTA ----
+ * Same results as the four stage calls, without materialising the raw or the aggregated
+ * DSI.  Works on the disparity slab [d_first, d_first + d_count) of the D = p->disp_n
+ * levels (independent per level: StcRawCosts.cpp:405-416, BoxFilter.cpp:119-125) and
+ * emits one signed 64-bit key per pixel:
+ *     key = (ordered_bits(best cost) << 32) | d        (d = global level index)
+ * ordered_bits() maps float order to int32 order, so min(key) over slabs (e.g. an
+ * int64 MIN all-reduce across GPUs) is OptWTA's winner with its lowest-d tie break. */
+int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                             size_t img_pitch, const smhip_match_params *p, int window,
+                             int d_first, int d_count, int64_t *d_keys);
+/* keys -> disparity and best cost (either may be NULL); n = W*H */
+int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, size_t n,
+                      int32_t *d_disp, float *d_best);
+/* convenience: all D levels on this device, then decode */
+int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                        size_t img_pitch, const smhip_match_params *p, int window,
+                        int32_t *d_disp, float *d_best);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

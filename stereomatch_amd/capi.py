@@ -1,0 +1,237 @@
+"""ctypes binding of the C-ABI in include/smhip.h (stereomatch_amd/lib/libsmhip.so).
+
+This is plumbing for Python callers (tests, bench.py); the compute is entirely in the
+HIP library.  There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsmhip.so")
+
+# every symbol include/smhip.h declares
+SYMBOLS = [
+    "smhip_init", "smhip_shutdown", "smhip_last_error", "smhip_set_stream", "smhip_sync",
+    "smhip_workspace_bytes", "smhip_malloc", "smhip_free", "smhip_memcpy_h2d",
+    "smhip_memcpy_d2h", "smhip_memcpy_d2d", "smhip_memcpy2d_h2d", "smhip_memcpy2d_d2h", "smhip_match_outside",
+    "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_convolve_14641",
+    "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
+    "smhip_keys_decode", "smhip_fused_box_wta",
+]
+
+
+class SmhipError(RuntimeError):
+    """Non-zero status from the C-ABI; the host driver turns these into CError
+    (Error.h:23-32), here they are Python exceptions carrying smhip_last_error()."""
+
+    def __init__(self, code, msg):
+        super().__init__("smhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class MatchParams(C.Structure):
+    """`smhip_match_params` (replaces LineProcessStruct, CudaRawCosts.h:97-114)."""
+
+    _fields_ = [
+        ("width", C.c_int), ("height", C.c_int), ("n_bands", C.c_int),
+        ("disp_min", C.c_int), ("disp_num", C.c_int), ("disp_den", C.c_int),
+        ("disp_n", C.c_int), ("frame_diff_sign", C.c_int),
+        ("match_fn", C.c_int), ("match_interp", C.c_int), ("match_max", C.c_int),
+        ("match_interval", C.c_int), ("match_interpolated", C.c_int),
+    ]
+
+
+def match_params(width, height, n_bands, disp_n, disp_min=0, disp_num=1, disp_den=1,
+                 frame_diff_sign=1, match_fn=1, match_interp=3, match_max=1000,
+                 match_interval=0, match_interpolated=0):
+    return MatchParams(width, height, n_bands, disp_min, disp_num, disp_den, disp_n,
+                       frame_diff_sign, match_fn, match_interp, match_max, match_interval,
+                       match_interpolated)
+
+
+_lib = None
+
+
+def load():
+    """Loads libsmhip.so and declares prototypes.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, ci, cf = C.c_void_p, C.c_size_t, C.c_int, C.c_float
+    pp = C.POINTER(MatchParams)
+    L.smhip_init.argtypes = [ci, C.POINTER(vp)]
+    L.smhip_shutdown.argtypes = [vp]
+    L.smhip_last_error.restype = C.c_char_p
+    L.smhip_last_error.argtypes = []
+    L.smhip_set_stream.argtypes = [vp, vp]
+    L.smhip_sync.argtypes = [vp]
+    L.smhip_workspace_bytes.restype = sz
+    L.smhip_workspace_bytes.argtypes = [vp]
+    L.smhip_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.smhip_free.argtypes = [vp, vp]
+    L.smhip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.smhip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.smhip_memcpy_d2d.argtypes = [vp, vp, vp, sz]
+    L.smhip_memcpy2d_h2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+    L.smhip_memcpy2d_d2h.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+    L.smhip_match_outside.restype = cf
+    L.smhip_match_outside.argtypes = [pp]
+    L.smhip_raw_costs.argtypes = [vp, vp, vp, sz, pp, vp, sz]
+    L.smhip_box_filter.argtypes = [vp, vp, ci, ci, ci, sz, ci, ci, ci]
+    L.smhip_min_filter.argtypes = [vp, vp, ci, ci, ci, sz, ci, ci]
+    L.smhip_convolve_14641.argtypes = [vp, vp, ci, ci, ci, sz]
+    L.smhip_diffusion_iter.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf]
+    L.smhip_pad_costs.argtypes = [vp, vp, sz, pp]
+    L.smhip_wta.argtypes = [vp, vp, ci, ci, ci, sz, vp, vp]
+    L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
+    L.smhip_keys_decode.argtypes = [vp, vp, sz, vp, vp]
+    L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
+    for name in SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("smhip_last_error", "smhip_workspace_bytes", "smhip_match_outside"):
+            f.restype = ci
+    _lib = L
+    return L
+
+
+class DeviceBuffer:
+    """A device allocation owned by a Context (or a borrowed pointer, e.g. a torch tensor)."""
+
+    def __init__(self, ctx, ptr, nbytes, owned=True):
+        self.ctx, self.ptr, self.nbytes, self.owned = ctx, ptr, nbytes, owned
+
+    def free(self):
+        if self.owned and self.ptr:
+            self.ctx._chk(self.ctx.L.smhip_free(self.ctx.h, self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    return int(x)
+
+
+class Context:
+    """One device context (`smhip_ctx`); not thread-safe, like the reference."""
+
+    def __init__(self, device=0):
+        self.L = load()
+        h = C.c_void_p()
+        rc = self.L.smhip_init(device, C.byref(h))
+        if rc:
+            raise SmhipError(rc, self.L.smhip_last_error().decode())
+        self.h = h
+
+    def _chk(self, rc):
+        if rc:
+            raise SmhipError(rc, self.L.smhip_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self._chk(self.L.smhip_shutdown(self.h))
+            self.h = None
+
+    def set_stream(self, stream_ptr):
+        self._chk(self.L.smhip_set_stream(self.h, stream_ptr))
+
+    def sync(self):
+        self._chk(self.L.smhip_sync(self.h))
+
+    def workspace_bytes(self):
+        return self.L.smhip_workspace_bytes(self.h)
+
+    # -- memory
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.L.smhip_malloc(self.h, nbytes, C.byref(p)))
+        return DeviceBuffer(self, p.value, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = self.alloc(max(arr.nbytes, 1))
+        if arr.nbytes:
+            self._chk(self.L.smhip_memcpy_h2d(self.h, buf.ptr, arr.ctypes.data, arr.nbytes))
+        return buf
+
+    def download(self, buf, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._chk(self.L.smhip_memcpy_d2h(self.h, out.ctypes.data, _ptr(buf), out.nbytes))
+        return out
+
+    def copy_d2d(self, dst, src, nbytes):
+        self._chk(self.L.smhip_memcpy_d2d(self.h, _ptr(dst), _ptr(src), nbytes))
+
+    def upload_pitched(self, arr2d_bytes, d_pitch):
+        """arr2d_bytes: uint8 [rows, h_pitch] host array; copies width=min pitch."""
+        rows, h_pitch = arr2d_bytes.shape
+        buf = self.alloc(rows * d_pitch)
+        self._chk(self.L.smhip_memcpy2d_h2d(self.h, buf.ptr, d_pitch, arr2d_bytes.ctypes.data,
+                                            h_pitch, min(h_pitch, d_pitch), rows))
+        return buf
+
+    def download_pitched(self, buf, d_pitch, rows, h_pitch, width_bytes):
+        out = np.zeros((rows, h_pitch), np.uint8)
+        self._chk(self.L.smhip_memcpy2d_d2h(self.h, out.ctypes.data, h_pitch, _ptr(buf), d_pitch,
+                                            width_bytes, rows))
+        return out
+
+    # -- operators (arguments as in include/smhip.h)
+    def match_outside(self, p):
+        return float(self.L.smhip_match_outside(C.byref(p)))
+
+    def raw_costs(self, d_ref, d_mtc, img_pitch, p, d_cost, row_elems):
+        self._chk(self.L.smhip_raw_costs(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch, C.byref(p),
+                                         _ptr(d_cost), row_elems))
+
+    def box_filter(self, d_cost, w, h, nb, row_elems, x_width, y_width=None, average=True):
+        y_width = x_width if y_width is None else y_width
+        self._chk(self.L.smhip_box_filter(self.h, _ptr(d_cost), w, h, nb, row_elems, x_width,
+                                          y_width, int(average)))
+
+    def min_filter(self, d_cost, w, h, nb, row_elems, x_width, y_width=None):
+        y_width = x_width if y_width is None else y_width
+        self._chk(self.L.smhip_min_filter(self.h, _ptr(d_cost), w, h, nb, row_elems, x_width,
+                                          y_width))
+
+    def convolve_14641(self, d_cost, w, h, nb, row_elems):
+        self._chk(self.L.smhip_convolve_14641(self.h, _ptr(d_cost), w, h, nb, row_elems))
+
+    def diffusion_iter(self, d_src, d_dst, d_cost0, w, h, nb, row_elems, lam, beta):
+        self._chk(self.L.smhip_diffusion_iter(self.h, _ptr(d_src), _ptr(d_dst), _ptr(d_cost0),
+                                              w, h, nb, row_elems, lam, beta))
+
+    def pad_costs(self, d_cost, row_elems, p):
+        self._chk(self.L.smhip_pad_costs(self.h, _ptr(d_cost), row_elems, C.byref(p)))
+
+    def wta(self, d_cost, w, h, nb, row_elems, d_disp, d_best):
+        self._chk(self.L.smhip_wta(self.h, _ptr(d_cost), w, h, nb, row_elems, _ptr(d_disp),
+                                   _ptr(d_best)))
+
+    def fused_box_wta_keys(self, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_keys):
+        self._chk(self.L.smhip_fused_box_wta_keys(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
+                                                  C.byref(p), window, d_first, d_count,
+                                                  _ptr(d_keys)))
+
+    def keys_decode(self, d_keys, n, d_disp, d_best):
+        self._chk(self.L.smhip_keys_decode(self.h, _ptr(d_keys), n, _ptr(d_disp), _ptr(d_best)))
+
+    def fused_box_wta(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
+        self._chk(self.L.smhip_fused_box_wta(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
+                                             C.byref(p), window, _ptr(d_disp), _ptr(d_best)))

@@ -1,0 +1,546 @@
+// smhip_api.hip -- the C-ABI of include/smhip.h: argument checks, workspace, launches.
+#include "../../include/smhip.h"
+#include "smhip_kernels.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess)                                                           \
+            return fail(e_ == hipErrorOutOfMemory ? SMHIP_ENOMEM : SMHIP_EHIP,          \
+                        "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum { WS_TMP = 0, WS_BT = 1, WS_KEYS = 2, WS_COUNT = 3 };
+
+}  // namespace
+
+struct smhip_ctx {
+    int device;
+    hipStream_t stream;
+    void *ws[WS_COUNT];
+    size_t ws_bytes[WS_COUNT];
+};
+
+namespace {
+
+// grow-only device workspace slot
+int ws_get(smhip_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            HIP_TRY(hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        HIP_TRY(hipMalloc(&ctx->ws[slot], bytes));
+        ctx->ws_bytes[slot] = bytes;
+    }
+    *out = ctx->ws[slot];
+    return SMHIP_OK;
+}
+
+int check_ctx(smhip_ctx *ctx)
+{
+    if (!ctx)
+        return fail(SMHIP_EINVAL, "null context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return SMHIP_OK;
+}
+
+int check_dsi(const void *d_cost, int w, int h, int nb, size_t row_elems)
+{
+    if (!d_cost)
+        return fail(SMHIP_EINVAL, "null DSI pointer");
+    if (w <= 0 || h <= 0 || nb <= 0)
+        return fail(SMHIP_EINVAL, "bad DSI shape %dx%dx%d", w, h, nb);
+    if (row_elems < (size_t)w * nb)
+        return fail(SMHIP_EINVAL, "row_elems %zu < width*bands %zu", row_elems, (size_t)w * nb);
+    if ((size_t)w * nb > 0x7FFFFFFFul)
+        return fail(SMHIP_EINVAL, "width*bands exceeds 2^31");
+    return SMHIP_OK;
+}
+
+int check_params(const smhip_match_params *p, const void *d_ref, const void *d_mtc, size_t pitch)
+{
+    if (!p || !d_ref || !d_mtc)
+        return fail(SMHIP_EINVAL, "null argument");
+    if (p->width <= 0 || p->height <= 0)
+        return fail(SMHIP_EINVAL, "bad image shape %dx%d", p->width, p->height);
+    if (p->n_bands != 1 && p->n_bands != 4)   // StereoIO.cpp:76-81
+        return fail(SMHIP_EINVAL, "number of bands (%d) not supported by stereo matcher", p->n_bands);
+    if (pitch < (size_t)p->width * p->n_bands)
+        return fail(SMHIP_EINVAL, "image pitch %zu < width*bands", pitch);
+    if (p->disp_n < 2)                        // StereoMatcher.cpp:158-159
+        return fail(SMHIP_EINVAL, "too few disparity levels (%d)", p->disp_n);
+    if (p->match_fn != 1 && p->match_fn != 2)
+        return fail(SMHIP_EINVAL, "unknown match_fn %d", p->match_fn);
+    if (p->disp_num < 1 || p->disp_den < 1)
+        return fail(SMHIP_EINVAL, "bad disparity step %d/%d", p->disp_num, p->disp_den);
+    if (p->disp_den != 1)
+        return fail(SMHIP_EINVAL, "disp_step < 1 (sub-pixel DSI, den=%d) is not implemented on the device",
+                    p->disp_den);
+    if (p->frame_diff_sign != 1 && p->frame_diff_sign != -1)
+        return fail(SMHIP_EINVAL, "frame_diff_sign must be +1 or -1");
+    return SMHIP_OK;
+}
+
+int cutoff_of(const smhip_match_params *p)
+{
+    return p->match_fn == 2 ? p->match_max * p->match_max : abs(p->match_max);
+}
+
+int outside_of(const smhip_match_params *p)
+{
+    int worst = p->n_bands * (p->match_fn == 2 ? 255 * 255 : 255);
+    int c = cutoff_of(p);
+    return worst < c ? worst : c;
+}
+
+// Fills RawArgs for levels [d_first, d_first+d_count); runs the BT pre-pass when needed.
+int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t pitch,
+                const smhip_match_params *p, int d_first, int d_count, smk::RawArgs *a)
+{
+    int W = p->width, H = p->height, nb = p->n_bands;
+    a->pitch = pitch;
+    a->W = W; a->H = H; a->nb = nb; a->D = d_count;
+    a->dstep = -p->frame_diff_sign * p->disp_num;
+    a->disp0 = -p->frame_diff_sign * (p->disp_den * p->disp_min) + d_first * a->dstep;
+    a->sd = p->match_fn == 2;
+    a->cutoff = cutoff_of(p);
+    a->outside = outside_of(p);
+    a->rmn = d_ref; a->rmx = nullptr;
+    a->mmn = d_mtc; a->mmx = nullptr;
+    if (p->match_interval) {
+        size_t img = pitch * H;
+        void *bt = nullptr;
+        int rc = ws_get(ctx, WS_BT, img * 4, &bt);
+        if (rc) return rc;
+        uint8_t *b = (uint8_t *)bt;
+        dim3 grid((W * nb + 255) / 256, H);
+        smk::bt_minmax_kernel<<<grid, 256, 0, ctx->stream>>>(d_mtc, b, b + img, pitch, W, H, nb);
+        a->mmn = b; a->mmx = b + img;
+        if (p->match_interpolated) {
+            smk::bt_minmax_kernel<<<grid, 256, 0, ctx->stream>>>(d_ref, b + 2 * img, b + 3 * img,
+                                                                 pitch, W, H, nb);
+            a->rmn = b + 2 * img; a->rmx = b + 3 * img;
+        } else {
+            a->rmx = d_ref;     // point interval [R, R] (StcRawCosts.cpp:410-411)
+        }
+        HIP_TRY(hipGetLastError());
+    }
+    return SMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *smhip_last_error(void) { return g_err; }
+
+int smhip_init(int device, smhip_ctx **out)
+{
+    if (!out)
+        return fail(SMHIP_EINVAL, "null context pointer");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n)
+        return fail(SMHIP_EINVAL, "device %d out of range (%d devices)", device, n);
+    HIP_TRY(hipSetDevice(device));
+    smhip_ctx *ctx = (smhip_ctx *)calloc(1, sizeof(smhip_ctx));
+    if (!ctx)
+        return fail(SMHIP_ENOMEM, "out of host memory");
+    ctx->device = device;
+    ctx->stream = nullptr;
+    *out = ctx;
+    return SMHIP_OK;
+}
+
+int smhip_shutdown(smhip_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < WS_COUNT; i++)
+        if (ctx->ws[i])
+            HIP_TRY(hipFree(ctx->ws[i]));
+    free(ctx);
+    return SMHIP_OK;
+}
+
+int smhip_set_stream(smhip_ctx *ctx, void *hip_stream)
+{
+    if (!ctx)
+        return fail(SMHIP_EINVAL, "null context");
+    ctx->stream = (hipStream_t)hip_stream;
+    return SMHIP_OK;
+}
+
+int smhip_sync(smhip_ctx *ctx)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SMHIP_OK;
+}
+
+size_t smhip_workspace_bytes(const smhip_ctx *ctx)
+{
+    size_t s = 0;
+    if (ctx)
+        for (int i = 0; i < WS_COUNT; i++)
+            s += ctx->ws_bytes[i];
+    return s;
+}
+
+int smhip_malloc(smhip_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_ptr || bytes == 0)
+        return fail(SMHIP_EINVAL, "bad allocation request");
+    HIP_TRY(hipMalloc(d_ptr, bytes));
+    return SMHIP_OK;
+}
+
+int smhip_free(smhip_ctx *ctx, void *d_ptr)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d_ptr));
+    return SMHIP_OK;
+}
+
+int smhip_memcpy_h2d(smhip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SMHIP_OK;
+}
+
+int smhip_memcpy_d2h(smhip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SMHIP_OK;
+}
+
+int smhip_memcpy_d2d(smhip_ctx *ctx, void *d_dst, const void *d_src, size_t bytes)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return SMHIP_OK;
+}
+
+int smhip_memcpy2d_h2d(smhip_ctx *ctx, void *d_dst, size_t d_pitch, const void *h_src,
+                       size_t h_pitch, size_t width_bytes, size_t rows)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(d_dst, d_pitch, h_src, h_pitch, width_bytes, rows,
+                             hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SMHIP_OK;
+}
+
+int smhip_memcpy2d_d2h(smhip_ctx *ctx, void *h_dst, size_t h_pitch, const void *d_src,
+                       size_t d_pitch, size_t width_bytes, size_t rows)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(h_dst, h_pitch, d_src, d_pitch, width_bytes, rows,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return SMHIP_OK;
+}
+
+float smhip_match_outside(const smhip_match_params *p)
+{
+    return p ? (float)outside_of(p) : 0.0f;
+}
+
+int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                    size_t img_pitch, const smhip_match_params *p, float *d_cost,
+                    size_t row_elems)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_params(p, d_ref, d_mtc, img_pitch);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, p->width, p->height, p->disp_n, row_elems);
+    if (rc) return rc;
+    smk::RawArgs a;
+    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, 0, p->disp_n, &a);
+    if (rc) return rc;
+    dim3 grid((p->width * p->disp_n + 255) / 256, p->height);
+    smk::raw_costs_kernel<<<grid, 256, 0, ctx->stream>>>(a, d_cost, row_elems);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t row_elems,
+                     int x_width, int y_width, int average)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (x_width != y_width)   // BoxFilter.cpp:179-180
+        return fail(SMHIP_EINVAL, "BoxFilter: xWidth != yWidth not implemented yet");
+    int win = x_width;
+    if (win < 1)
+        return fail(SMHIP_EINVAL, "BoxFilter: bad window %d", win);
+    if (win - win / 2 >= w || win - win / 2 >= h)   // borderIndex asserts, BoxFilter.cpp:37,51
+        return fail(SMHIP_EINVAL, "BoxFilter: window %d too large for %dx%d (double wrapping)", win, w, h);
+    void *tmp = nullptr;
+    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    if (rc) return rc;
+    float scale = (float)(average ? 1.0 / win : 1);   // BoxFilter.cpp:89
+    long nh = (long)h * nb;
+    smk::box_lines_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
+        d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, win, scale);
+    long nv = (long)w * nb;
+    smk::box_lines_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
+        (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, win, scale);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t row_elems,
+                     int x_width, int y_width)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (x_width < 1 || y_width < 1)
+        return fail(SMHIP_EINVAL, "MinFilter: bad window %dx%d", x_width, y_width);
+    void *tmp = nullptr;
+    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    if (rc) return rc;
+    dim3 grid((w * nb + 255) / 256, h);
+    smk::min_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems, x_width);
+    smk::min_v_kernel<<<grid, 256, 0, ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems,
+                                                    y_width);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_convolve_14641(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t row_elems)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    void *tmp = nullptr;
+    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    if (rc) return rc;
+    dim3 grid((w * nb + 255) / 256, h);
+    smk::binom_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems);
+    smk::binom_v_kernel<<<grid, 256, 0, ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst, const float *d_cost0,
+                         int w, int h, int nb, size_t row_elems, float lambda, float beta)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_src, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_dst || d_dst == d_src)
+        return fail(SMHIP_EINVAL, "diffusion needs distinct source and destination");
+    if (beta > 0.0f && !d_cost0)
+        return fail(SMHIP_EINVAL, "membrane model (beta > 0) needs the initial DSI");
+    float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
+    float lb = lambda * beta;            // :132
+    dim3 grid((w * nb + 255) / 256, h);
+    smk::diffusion_kernel<<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, d_cost0, w, nb, h, row_elems,
+                                                        lambda, a, lb, beta > 0.0f);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip_match_params *p)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!p)
+        return fail(SMHIP_EINVAL, "null parameters");
+    rc = check_dsi(d_cost, p->width, p->height, p->disp_n, row_elems);
+    if (rc) return rc;
+    if (p->disp_den != 1)
+        return fail(SMHIP_EINVAL, "disp_step < 1 is not implemented on the device");
+    int dstep = -p->frame_diff_sign * p->disp_num;
+    int disp0 = -p->frame_diff_sign * p->disp_min;
+    int dlast = disp0 + (p->disp_n - 1) * dstep;
+    int maxpad = abs(disp0) > abs(dlast) ? abs(disp0) : abs(dlast);
+    if (maxpad > p->width) maxpad = p->width;
+    if (maxpad == 0)
+        return SMHIP_OK;
+    dim3 grid((p->disp_n * maxpad + 255) / 256, p->height);
+    smk::pad_costs_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, row_elems, p->width, p->disp_n, disp0,
+                                                        dstep, maxpad, smhip_match_outside(p));
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t row_elems,
+              int32_t *d_disp, float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_disp && !d_best)
+        return fail(SMHIP_EINVAL, "no output requested");
+    long n_pix = (long)w * h;
+    if (nb >= 64) {
+        long blocks = (n_pix + 3) / 4;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        smk::wta_wave_kernel<<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems,
+                                                                        d_disp, d_best);
+    } else {
+        smk::wta_thread_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+            d_cost, w, h, nb, row_elems, d_disp, d_best);
+    }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, size_t n, int32_t *d_disp, float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_keys || n == 0 || (!d_disp && !d_best))
+        return fail(SMHIP_EINVAL, "bad decode request");
+    smk::keys_decode_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(
+        (const long long *)d_keys, n, d_disp, d_best);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                             size_t img_pitch, const smhip_match_params *p, int window,
+                             int d_first, int d_count, int64_t *d_keys)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_params(p, d_ref, d_mtc, img_pitch);
+    if (rc) return rc;
+    if (!d_keys)
+        return fail(SMHIP_EINVAL, "null key buffer");
+    if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
+        return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count,
+                    p->disp_n);
+    int W = p->width, H = p->height;
+    if (window < 1 || window - window / 2 >= W || window - window / 2 >= H)
+        return fail(SMHIP_EINVAL, "BoxFilter: window %d unusable for %dx%d", window, W, H);
+
+    // padded slab width: power of two below 64, else a multiple of 64 (of 256 above 256)
+    int Dp, CH;
+    if (d_count <= 32) {
+        Dp = 2;
+        while (Dp < d_count) Dp <<= 1;
+        CH = Dp;
+    } else if (d_count <= 256) {
+        Dp = (d_count + 63) / 64 * 64;
+        CH = Dp;
+    } else {
+        Dp = (d_count + 255) / 256 * 256;
+        CH = 256;
+    }
+    int n_chunks = Dp / CH;
+    size_t n_pix = (size_t)W * H;
+
+    smk::RawArgs a;
+    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
+    if (rc) return rc;
+    void *T = nullptr;
+    rc = ws_get(ctx, WS_TMP, n_pix * Dp * sizeof(float), &T);
+    if (rc) return rc;
+    long long *kout = (long long *)d_keys;
+    if (n_chunks > 1) {
+        void *part = nullptr;
+        rc = ws_get(ctx, WS_KEYS, n_pix * n_chunks * sizeof(long long), &part);
+        if (rc) return rc;
+        kout = (long long *)part;
+    }
+    float scale = (float)(1.0 / window);
+    float outside = smhip_match_outside(p);
+
+    long chains = (long)H * Dp;
+    smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
+        a, (float *)T, Dp, window, scale);
+
+    int tpb = CH < 64 ? 256 : CH * (256 / CH);
+    int pix_per_blk = tpb / CH;
+    dim3 grid((W + pix_per_blk - 1) / pix_per_blk, n_chunks);
+#define LAUNCH_B(SEG)                                                                          \
+    smk::fused_boxv_wta_kernel<SEG><<<grid, tpb, 0, ctx->stream>>>(                            \
+        (const float *)T, W, H, Dp, d_count, CH, CH, window, scale, a.disp0, a.dstep, outside, \
+        d_first, kout, n_pix)
+    switch (CH < 64 ? CH : 64) {
+    case 2: LAUNCH_B(2); break;
+    case 4: LAUNCH_B(4); break;
+    case 8: LAUNCH_B(8); break;
+    case 16: LAUNCH_B(16); break;
+    case 32: LAUNCH_B(32); break;
+    default: LAUNCH_B(64); break;
+    }
+#undef LAUNCH_B
+    if (n_chunks > 1)
+        smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+            kout, n_chunks, n_pix, (long long *)d_keys);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                        const smhip_match_params *p, int window, int32_t *d_disp, float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!p)
+        return fail(SMHIP_EINVAL, "null parameters");
+    if (!d_disp && !d_best)
+        return fail(SMHIP_EINVAL, "no output requested");
+    size_t n_pix = (size_t)p->width * p->height;
+    // keys live behind the per-chunk partials in the key workspace
+    int d_count = p->disp_n;
+    int n_chunks = d_count > 256 ? (d_count + 255) / 256 : 1;
+    void *kws = nullptr;
+    rc = ws_get(ctx, WS_KEYS, n_pix * (size_t)(n_chunks + 1) * sizeof(long long), &kws);
+    if (rc) return rc;
+    int64_t *keys = (int64_t *)kws + n_pix * (size_t)n_chunks;
+    rc = smhip_fused_box_wta_keys(ctx, d_ref, d_mtc, img_pitch, p, window, 0, d_count, keys);
+    if (rc) return rc;
+    return smhip_keys_decode(ctx, keys, n_pix, d_disp, d_best);
+}
+
+}  // extern "C"

@@ -1,0 +1,188 @@
+"""Python mirror of the reference's pipeline driver for the hot path.
+
+`StereoMatcher` keeps the reference's parameter names (StereoParameters.h:50-242) and stage
+names (StereoMatcher.h:78-109: RawCosts / Aggregate / Optimize / Refine) and sequences the
+C-ABI calls of include/smhip.h exactly as ComputeCorrespondence (StereoMatcher.cpp:155-177)
+sequences the CPU stages.  The DSI stays resident on the device between stages.  All compute
+runs in libsmhip.so; this file holds no arithmetic beyond the O(W*H) depth-map scaling that
+the reference also does on the host (StcRefine.cpp:34-39, StereoMatcher.cpp:177).
+"""
+import numpy as np
+
+from . import capi
+
+# enums, StereoParameters.h:33-136
+eAD, eSD = 1, 2
+eLinear, eCubic = 1, 3
+eBox, eBinomial, eDiffusion, eMembrane, eBayesian = 1, 2, 3, 4, 5
+eNoOpt, eWTA = 0, 1
+
+
+def _round(x):  # ROUND, StereoMatcher.cpp:36
+    return int(x + 0.5) if x >= 0 else int(x - 0.5)
+
+
+class StereoParameters:
+    """Algorithm + sequence parameters with the defaults of ReInitializeSeqParams /
+    ReInitializeAlgParams (StereoParameters.cpp:33-116); only the hot-path subset."""
+
+    def __init__(self, **kw):
+        self.ReInitializeSeqParams()
+        self.ReInitializeAlgParams()
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise KeyError("unknown parameter %s" % k)
+            setattr(self, k, v)
+
+    def ReInitializeSeqParams(self):
+        self.frame_ref, self.frame_match = 0, 1
+        self.disp_min, self.disp_max, self.disp_step = 0, 7, 1.0
+        self.disp_n, self.disp_scale = 0, 1.0
+        self.verbose = 3
+
+    def ReInitializeAlgParams(self):
+        self.match_fn, self.match_interp, self.match_max = eAD, eCubic, 1000
+        self.match_interval, self.match_interpolated = 0, 0
+        self.aggr_fn, self.aggr_window_size, self.aggr_iter = eBox, 7, 1
+        self.aggr_minfilter, self.aggr_subpixel, self.aggr_collapse = 0, 0, 0
+        self.diff_lambda, self.diff_beta = 0.15, 0.5
+        self.opt_fn = eWTA
+        self.refine_subpix = 0
+        self.eval_match_quality = 0
+
+
+class StereoMatcher(StereoParameters):
+    """Device-resident pipeline: images in, int32 disparity + best cost + uint8 depth out."""
+
+    def __init__(self, ctx=None, device=0, **kw):
+        super().__init__(**kw)
+        self.ctx = ctx if ctx is not None else capi.Context(device)
+        self.allow_fused = True
+        self.used_fused = False
+        self._bufs = {}
+
+    # -- device buffers (re-used across calls while the size fits)
+    def _buf(self, name, nbytes):
+        b = self._bufs.get(name)
+        if b is None or b.nbytes < nbytes:
+            if b is not None:
+                b.free()
+            b = self.ctx.alloc(nbytes)
+            self._bufs[name] = b
+        return b
+
+    def _derive(self, shape):
+        # StereoMatcher.cpp:60-82
+        h, w, nb = shape
+        if self.disp_step <= 0:
+            raise ValueError("ComputeCorrespondence: disp_step must integer N or 1.0/N")
+        self.m_frame_diff_sign = 1 if self.frame_match - self.frame_ref > 0 else -1
+        self.m_disp_num = 1 if self.disp_step < 1.0 else _round(self.disp_step)
+        self.m_disp_den = _round(1.0 / self.disp_step) if self.disp_step < 1.0 else 1
+        self.disp_step = float(np.float32(self.m_disp_num) / np.float32(self.m_disp_den))
+        inv = np.float32(self.m_disp_den) / np.float32(self.m_disp_num)
+        self.disp_n = int(np.float32(inv * np.float32(self.disp_max - self.disp_min))) + 1
+        self.m_disp_n = self.disp_n
+        if self.m_disp_n < 2:
+            raise ValueError("ComputeCorrespondence: too few disparity levels (%d)" % self.m_disp_n)
+        self.m_params = capi.match_params(
+            w, h, nb, self.m_disp_n, disp_min=self.disp_min, disp_num=self.m_disp_num,
+            disp_den=self.m_disp_den, frame_diff_sign=self.m_frame_diff_sign,
+            match_fn=self.match_fn, match_interp=self.match_interp, match_max=self.match_max,
+            match_interval=1 if self.match_interval else 0,
+            match_interpolated=self.match_interpolated)
+        self.m_match_outside = self.ctx.match_outside(self.m_params)
+
+    def _fusable(self):
+        # box x1 + WTA and nobody needs the full DSI afterwards
+        return (self.allow_fused and self.aggr_fn == eBox and self.aggr_iter == 1
+                and self.aggr_minfilter <= 1 and self.opt_fn == eWTA and not self.refine_subpix
+                and not self.aggr_subpixel and not self.aggr_collapse
+                and not self.eval_match_quality and self.m_disp_den == 1)
+
+    def ComputeCorrespondence(self, ref, mtc):
+        """ref, mtc: uint8 [H, W, nBands] host arrays.  Returns (disparity, best_cost, depth)."""
+        ref = np.ascontiguousarray(ref, np.uint8)
+        mtc = np.ascontiguousarray(mtc, np.uint8)
+        if ref.ndim == 2:
+            ref, mtc = ref[:, :, None], mtc[:, :, None]
+        if ref.shape != mtc.shape:
+            raise ValueError("ComputeCorrespondence: reference and matching not the same size")
+        self._derive(ref.shape)
+        h, w, nb = ref.shape
+        self.m_pitch = w * nb
+        self.d_ref = self._buf("ref", ref.nbytes)
+        self.d_mtc = self._buf("mtc", mtc.nbytes)
+        c = self.ctx
+        c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_ref.ptr, ref.ctypes.data, ref.nbytes))
+        c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_mtc.ptr, mtc.ctypes.data, mtc.nbytes))
+        self.d_disp = self._buf("disp", w * h * 4)
+        self.d_best = self._buf("best", w * h * 4)
+        self.used_fused = self._fusable()
+        if self.used_fused:
+            c.fused_box_wta(self.d_ref, self.d_mtc, self.m_pitch, self.m_params,
+                            self.aggr_window_size, self.d_disp, self.d_best)
+        else:
+            self.RawCosts()
+            self.Aggregate()
+            self.Optimize()
+        disp = c.download(self.d_disp, (h, w), np.int32)
+        best = c.download(self.d_best, (h, w), np.float32)
+        return disp, best, self.Refine(disp)
+
+    def RawCosts(self):  # StcRawCosts.cpp:229
+        p = self.m_params
+        self.m_row_elems = p.width * p.disp_n
+        self.d_cost = self._buf("cost", self.m_row_elems * p.height * 4)
+        self.ctx.raw_costs(self.d_ref, self.d_mtc, self.m_pitch, p, self.d_cost, self.m_row_elems)
+
+    def Aggregate(self):  # StcAggregate.cpp:255-365
+        p, c = self.m_params, self.ctx
+        w, h, nb, re = p.width, p.height, p.disp_n, self.m_row_elems
+        nbytes = re * h * 4
+        beta = 0.0 if self.aggr_fn == eDiffusion else self.diff_beta   # :305
+        cost0 = None
+        if self.aggr_fn == eMembrane and beta > 0.0 and self.aggr_iter > 0:
+            cost0 = self._buf("cost0", nbytes)                          # :262
+            self._copy(cost0, self.d_cost, nbytes)
+        for _ in range(self.aggr_iter):
+            if self.aggr_fn == eBox:
+                c.box_filter(self.d_cost, w, h, nb, re, self.aggr_window_size)
+            elif self.aggr_fn == eBinomial:
+                c.convolve_14641(self.d_cost, w, h, nb, re)
+            elif self.aggr_fn in (eDiffusion, eMembrane):
+                other = self._buf("cost2", nbytes)                      # StcDiffusion.cpp:58-63
+                c.diffusion_iter(self.d_cost, other, cost0, w, h, nb, re, self.diff_lambda, beta)
+                self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+                self.d_cost = other
+            else:
+                raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
+        if self.aggr_minfilter > 1:                                      # :351-360
+            c.min_filter(self.d_cost, w, h, nb, re, self.aggr_minfilter)
+        c.pad_costs(self.d_cost, re, p)                                  # :365
+
+    def Optimize(self):  # StcOptimize.cpp:162-280, WTA only
+        if self.opt_fn != eWTA:
+            raise ValueError("CStereoMatcher::Optimize(): only opt_fn = eWTA is on the device path")
+        p = self.m_params
+        self.ctx.wta(self.d_cost, p.width, p.height, p.disp_n, self.m_row_elems, self.d_disp,
+                     self.d_best)
+
+    def Refine(self, disp):  # StcRefine.cpp:34-39 + StereoMatcher.cpp:177 (Convert.cpp:25-53)
+        f32 = np.float32
+        d_off = f32(self.disp_min)
+        fd = disp.astype(f32)
+        if f32(self.disp_step) != 1.0 or d_off != 0.0:
+            fd = fd * f32(self.disp_step) + d_off
+        off = f32(np.float64(f32(-self.disp_min) * f32(self.disp_scale)) + 0.5)
+        v = fd
+        if f32(self.disp_scale) != 1.0 or off != 0.0:
+            v = fd * f32(self.disp_scale) + off
+        return np.clip(v, f32(0), f32(255)).astype(np.uint8)
+
+    def download_cost(self):
+        p = self.m_params
+        return self.ctx.download(self.d_cost, (p.height, p.width, p.disp_n), np.float32)
+
+    def _copy(self, dst, src, nbytes):
+        self.ctx.copy_d2d(dst, src, nbytes)

@@ -1,0 +1,50 @@
+"""Generates tests/golden/tsukuba_anchors.json.
+
+`reference`: values recorded from the reference's own CPU path (they are
+copied here verbatim, this script does not run the reference).  `oracle`: md5 of the disparity
+PGM that oracle/sm_oracle.c produces for every exp1 / exp2 / exp4-style configuration.
+Run from the repository root:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import oracle as O  # noqa: E402
+from stereomatch_amd import pnm  # noqa: E402
+import util  # noqa: E402
+
+REFERENCE = {
+    "md5": {
+        "SSD09": "ef5a6af9c75265e128c9ab76604b87f2",
+        "SAD09b": "8015a7bb457366682e04f4f389674140",
+        "SSDmf09t20": "0cb69c3256202a1d2587502e41715bdc",
+        "SADbf04": "5534d6f647b7166ca4706534a335bd01",
+        "SADdiff10": "839f458ab4f316491509f43afd262ae9",
+    },
+    "final_energy": {"SSD09": 24421442.0},
+    "source": "BASELINE.md section 2 (reference CPU path, survey-stage probe build)",
+}
+
+
+def main():
+    d = os.path.join(ROOT, "tests", "golden", "tsukuba")
+    ref = pnm.read_image(os.path.join(d, "scene1.row3.col3.ppm"))
+    mtc = pnm.read_image(os.path.join(d, "scene1.row3.col4.ppm"))
+    h, w, b = ref.shape
+    out = {"reference": REFERENCE, "oracle": {"md5": {}, "final_energy": {}}}
+    for name, kw in util.exp_grid() + util.exp4_grid():
+        p = O.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+        _, _, depth, e = O.compute_correspondence(ref, mtc, p)
+        out["oracle"]["md5"][name] = util.md5(pnm.pgm_bytes(depth))
+        out["oracle"]["final_energy"][name] = e
+    with open(os.path.join(ROOT, "tests", "golden", "tsukuba_anchors.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote %d oracle vectors" % len(out["oracle"]["md5"]))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,34 @@
+"""The C-ABI library loads and exports every symbol include/smhip.h declares (no GPU)."""
+import ctypes
+import os
+import re
+
+from stereomatch_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "smhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smhip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_matches_binding():
+    assert header_symbols() == sorted(capi.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    assert os.path.exists(capi.LIB_PATH), "build libsmhip.so first (__graft_entry__.build())"
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+    capi.load()
+
+
+def test_match_outside_needs_no_gpu():
+    L = capi.load()
+    p = capi.match_params(384, 288, 4, 16, match_fn=2, match_max=1000)
+    assert L.smhip_match_outside(ctypes.byref(p)) == 4 * 255 * 255      # StcRawCosts.cpp:365-367
+    p = capi.match_params(384, 288, 4, 16, match_fn=1, match_max=20)
+    assert L.smhip_match_outside(ctypes.byref(p)) == 20

@@ -1,0 +1,179 @@
+"""Parity of every stage operator of the C-ABI against the oracle, bit for bit."""
+import numpy as np
+import pytest
+
+import util
+from stereomatch_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def up(ctx, a):
+    return ctx.upload(np.ascontiguousarray(a))
+
+
+def run_inplace(ctx, cost, fn, row_pad=0):
+    """Uploads cost [H,W,D] with `row_pad` extra floats per row, runs fn(buf, w, h, d, row_elems)."""
+    h, w, d = cost.shape
+    re = w * d + row_pad
+    host = np.full((h, re), np.float32(-12345.0))
+    host[:, :w * d] = cost.reshape(h, w * d)
+    buf = up(ctx, host)
+    fn(buf, w, h, d, re)
+    out = ctx.download(buf, (h, re), np.float32)
+    if row_pad:
+        assert np.all(out[:, w * d:] == np.float32(-12345.0)), "row padding was overwritten"
+    return out[:, :w * d].reshape(h, w, d)
+
+
+RAW_CASES = [
+    # w, h, b, D, dmin, sign, fn, mmax, interval, interpolated
+    (37, 11, 1, 9, 0, 1, 1, 1000, 0, 0),
+    (37, 11, 4, 9, 0, 1, 2, 1000, 0, 0),
+    (64, 9, 4, 16, 0, 1, 1, 20, 1, 0),
+    (50, 7, 1, 33, 2, 1, 2, 5, 1, 0),
+    (41, 8, 1, 12, 0, -1, 1, 1000, 1, 0),
+    (41, 8, 4, 12, 1, -1, 2, 50, 0, 0),
+    (45, 6, 4, 8, 0, 1, 1, 1000, 1, 1),
+    (130, 5, 1, 100, 0, 1, 1, 2, 1, 0),
+]
+
+
+@pytest.mark.parametrize("w,h,b,D,dmin,sign,fn,mmax,interval,interp", RAW_CASES)
+def test_raw_costs(gpu_ctx, oracle, w, h, b, D, dmin, sign, fn, mmax, interval, interp):
+    ref, mtc = synth.noise_pair(w, h, b, seed=synth.SEED_NOISE + D)
+    fr, fm = (0, 1) if sign > 0 else (1, 0)
+    po = oracle.make_params(w, h, b, disp_min=dmin, disp_max=dmin + D - 1, frame_ref=fr,
+                            frame_match=fm, match_fn=fn, match_max=mmax,
+                            match_interval=interval, match_interpolated=interp)
+    want = oracle.raw_costs(ref, mtc, po)
+    p = capi.match_params(w, h, b, D, disp_min=dmin, frame_diff_sign=sign, match_fn=fn,
+                          match_max=mmax, match_interval=interval, match_interpolated=interp)
+    assert gpu_ctx.match_outside(p) == oracle.match_outside(po)
+    d_ref, d_mtc = up(gpu_ctx, ref), up(gpu_ctx, mtc)
+    cost = gpu_ctx.alloc(w * h * D * 4)
+    gpu_ctx.raw_costs(d_ref, d_mtc, w * b, p, cost, w * D)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32), want, "raw costs")
+    # PadCosts on the same volume
+    gpu_ctx.pad_costs(cost, w * D, p)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32),
+                          oracle.pad_costs(want, po), "pad costs")
+
+
+def test_raw_costs_pitched_images(gpu_ctx, oracle):
+    """Images whose rows are padded to 8 bytes (Image.cpp:97-98): W*b = 37 -> pitch 40."""
+    w, h, b, D = 37, 6, 1, 8
+    ref, mtc = synth.noise_pair(w, h, b)
+    pitch = (w * b + 7) & ~7
+    def padded(img):
+        out = np.full((h, pitch), 255, np.uint8)
+        out[:, :w * b] = img.reshape(h, w * b)
+        return out
+    po = oracle.make_params(w, h, b, disp_max=D - 1, match_interval=1)
+    p = capi.match_params(w, h, b, D, match_interval=1)
+    cost = gpu_ctx.alloc(w * h * D * 4)
+    gpu_ctx.raw_costs(up(gpu_ctx, padded(ref)), up(gpu_ctx, padded(mtc)), pitch, p, cost, w * D)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32),
+                          oracle.raw_costs(ref, mtc, po), "pitched raw costs")
+
+
+SHAPES = [(13, 17, 5, 0), (20, 33, 16, 0), (9, 21, 3, 1), (24, 40, 64, 0), (12, 19, 100, 0),
+          (10, 15, 7, 1)]
+
+
+@pytest.mark.parametrize("h,w,d,pad", SHAPES)
+@pytest.mark.parametrize("win", [3, 4, 9])
+def test_box_filter(gpu_ctx, oracle, h, w, d, pad, win):
+    c = util.rand_dsi(h, w, d, 10 + win)
+    got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.box_filter(b, W, H, D, re, win), pad)
+    util.assert_bit_equal(got, oracle.box_filter(c, win), "box %d" % win)
+
+
+def test_box_filter_large_magnitude_drift(gpu_ctx, oracle):
+    """SSD magnitudes (outside = 260100) next to small costs: the running sum's rounding
+    drift must be reproduced exactly (hard parts)."""
+    c = util.rand_dsi(16, 48, 16, 3)
+    c[:, :5, :] = 260100.0
+    got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.box_filter(b, W, H, D, re, 9))
+    util.assert_bit_equal(got, oracle.box_filter(c, 9), "box drift")
+
+
+def test_box_filter_sum_mode(gpu_ctx, oracle):
+    c = util.rand_dsi(11, 14, 6, 4)
+    got = run_inplace(gpu_ctx, c,
+                      lambda b, W, H, D, re: gpu_ctx.box_filter(b, W, H, D, re, 5, average=False))
+    util.assert_bit_equal(got, oracle.box_filter(c, 5, average=False), "box sum")
+
+
+@pytest.mark.parametrize("h,w,d,pad", SHAPES)
+@pytest.mark.parametrize("win", [2, 3, 9])
+def test_min_filter(gpu_ctx, oracle, h, w, d, pad, win):
+    c = util.rand_dsi(h, w, d, 20 + win, "float")
+    got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.min_filter(b, W, H, D, re, win), pad)
+    util.assert_bit_equal(got, oracle.min_filter(c, win), "min %d" % win)
+
+
+@pytest.mark.parametrize("h,w,d,pad", SHAPES)
+def test_binomial(gpu_ctx, oracle, h, w, d, pad):
+    c = util.rand_dsi(h, w, d, 30, "float")
+    got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.convolve_14641(b, W, H, D, re), pad)
+    util.assert_bit_equal(got, oracle.convolve_14641(c), "binomial")
+    # iterate, as aggr_iter does (StcAggregate.cpp:265)
+    want = c
+    for _ in range(3):
+        want = oracle.convolve_14641(want)
+    def three(b, W, H, D, re):
+        for _ in range(3):
+            gpu_ctx.convolve_14641(b, W, H, D, re)
+    util.assert_bit_equal(run_inplace(gpu_ctx, c, three, pad), want, "binomial x3")
+
+
+@pytest.mark.parametrize("h,w,d,pad", SHAPES)
+@pytest.mark.parametrize("beta", [0.0, 0.5])
+def test_diffusion(gpu_ctx, oracle, h, w, d, pad, beta):
+    c = util.rand_dsi(h, w, d, 40, "float")
+    c0 = util.rand_dsi(h, w, d, 41, "float")
+    re = w * d + pad
+    def padded(a):
+        out = np.zeros((h, re), np.float32)
+        out[:, :w * d] = a.reshape(h, w * d)
+        return out
+    src, dst, b0 = up(gpu_ctx, padded(c)), gpu_ctx.alloc(h * re * 4), up(gpu_ctx, padded(c0))
+    gpu_ctx.diffusion_iter(src, dst, b0 if beta > 0 else None, w, h, d, re, 0.15, beta)
+    got = gpu_ctx.download(dst, (h, re), np.float32)[:, :w * d].reshape(h, w, d)
+    util.assert_bit_equal(got, oracle.diffusion_iter(c, 0.15, beta, c0), "diffusion")
+
+
+@pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (2, 5, 300)])
+def test_wta(gpu_ctx, oracle, h, w, d):
+    c = util.rand_dsi(h, w, d, 50)
+    c[0, 0, :] = 5.0
+    c[1, 3, 2] = c[1, 3, d - 1] = -1.0
+    c[2, 1, d - 1] = -0.0
+    c[2, 1, :d - 1] = 0.0
+    wd, wb = oracle.wta(c)
+    disp, best = gpu_ctx.alloc(h * w * 4), gpu_ctx.alloc(h * w * 4)
+    gpu_ctx.wta(up(gpu_ctx, c), w, h, d, w * d, disp, best)
+    assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
+    assert np.array_equal(gpu_ctx.download(best, (h, w), np.float32), wb)
+
+
+def test_error_reporting(gpu_ctx):
+    """Host misuse comes back as SMHIP_EINVAL with the reference's message (BoxFilter.cpp:179-180)."""
+    buf = gpu_ctx.alloc(64 * 64 * 4 * 4)
+    with pytest.raises(capi.SmhipError) as e:
+        gpu_ctx.box_filter(buf, 64, 64, 4, 256, 5, 7)
+    assert e.value.code == -1 and "xWidth != yWidth" in str(e.value)
+    with pytest.raises(capi.SmhipError):
+        gpu_ctx.box_filter(buf, 64, 64, 4, 100, 5)            # row_elems < w*d
+    p = capi.match_params(64, 64, 3, 8)
+    with pytest.raises(capi.SmhipError) as e:
+        gpu_ctx.raw_costs(buf, buf, 192, p, buf, 512)
+    assert "number of bands (3) not supported" in str(e.value)    # StereoIO.cpp:76-81
+    p = capi.match_params(64, 64, 1, 1)
+    with pytest.raises(capi.SmhipError) as e:
+        gpu_ctx.raw_costs(buf, buf, 64, p, buf, 64)
+    assert "too few disparity levels" in str(e.value)             # StereoMatcher.cpp:158-159
+    p = capi.match_params(64, 64, 1, 8, disp_den=2)
+    with pytest.raises(capi.SmhipError):
+        gpu_ctx.raw_costs(buf, buf, 64, p, buf, 512)

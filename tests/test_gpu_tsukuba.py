@@ -1,0 +1,60 @@
+"""BASELINE configs 1-2 on tsukuba: exp1 (9x9 box) and exp2 (+ 9x9 min filter) grids, exp4-style
+binomial / diffusion / membrane runs.  Disparity PGMs must be byte-identical to the reference's
+recorded md5s (five anchors) and to the oracle everywhere else."""
+import numpy as np
+import pytest
+
+import util
+from stereomatch_amd import matcher, pnm
+
+pytestmark = pytest.mark.gpu
+
+
+def run(gpu_ctx, tsukuba, kw, fused=True):
+    ref, mtc = tsukuba
+    m = matcher.StereoMatcher(ctx=gpu_ctx, **util.TSUKUBA_SEQ, **kw)
+    m.allow_fused = fused
+    disp, best, depth = m.ComputeCorrespondence(ref, mtc)
+    return m, disp, best, depth
+
+
+def test_reference_anchors(gpu_ctx, tsukuba):
+    a = util.anchors()["reference"]["md5"]
+    grid = dict(util.exp_grid() + util.exp4_grid())
+    for name, want in a.items():
+        for fused in (True, False):
+            _, _, _, depth = run(gpu_ctx, tsukuba, grid[name], fused)
+            assert util.md5(pnm.pgm_bytes(depth)) == want, (name, fused)
+
+
+def test_ssd09_data_energy(gpu_ctx, tsukuba, oracle):
+    """final_energy's data term is the raster-order float sum of the best costs
+    (StcGraphCut.cpp:56-59); with it the SSD09 energy matches the reference's 24421442."""
+    grid = dict(util.exp_grid())
+    m, disp, best, _ = run(gpu_ctx, tsukuba, grid["SSD09"])
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **grid["SSD09"])
+    odisp, obest, _, e = oracle.compute_correspondence(ref, mtc, p)
+    util.assert_bit_equal(disp, odisp, "SSD09 disparity")
+    util.assert_bit_equal(best, obest, "SSD09 best cost")
+    assert e == util.anchors()["reference"]["final_energy"]["SSD09"]
+
+
+@pytest.mark.parametrize("name,kw", util.exp_grid() + util.exp4_grid())
+def test_grid_vs_oracle_golden(gpu_ctx, tsukuba, name, kw):
+    want = util.anchors()["oracle"]["md5"][name]
+    _, _, _, depth = run(gpu_ctx, tsukuba, kw)
+    assert util.md5(pnm.pgm_bytes(depth)) == want, name
+
+
+@pytest.mark.parametrize("name", ["SAD09t02", "SSDmf09b", "SADbf04", "SADdiff10", "SADmem10b05"])
+def test_full_dsi_vs_oracle(gpu_ctx, tsukuba, oracle, name):
+    """Whole aggregated DSI (not only the winner) bit-identical to the oracle."""
+    kw = dict(util.exp_grid() + util.exp4_grid())[name]
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+    want = oracle.aggregate(oracle.raw_costs(ref, mtc, p), p)
+    m, _, _, _ = run(gpu_ctx, tsukuba, kw, fused=False)
+    util.assert_bit_equal(m.download_cost(), want, name)
