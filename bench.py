@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- cost-volume throughput of the fused raw-cost -> 9x9 box -> WTA hot path.
+
+N = 1 (BASELINE.json configs[2], the configuration the metric's target is quoted on):
+    synthetic rectified pair 1920x1080, b = 1, D = 256, BT-interpolated SAD
+    (match_fn 1, match_interval 1, match_max 1000), 9x9 box aggregation, PadCosts, WTA.
+N > 1: weak scaling by disparity slab -- every rank runs the same 256-level slab size on the
+    same image pair, the problem has D = 256*N levels, and the per-pixel (cost, d) keys are
+    min-reduced with ONE RCCL all-reduce (int64 MIN) per step, then decoded.
+
+A step = one pass of the hot path over the resident image pair (images already in HBM).
+value = (W*H*D_total voxels of all ranks) / (max-over-ranks wall time of K steps).
+
+The JSON line also carries `roofline` (dominant kernel, HIP events recorded inside the timed
+region on the launch stream), `roofline_fused` (both passes against the 8N + images + outputs
+algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the CPU oracle on one host core, on a
+bounded sample of the same workload; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--disp-per-gpu", type=int, default=256)
+    ap.add_argument("--window", type=int, default=9)
+    ap.add_argument("--bands", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=135,
+                    help="rows of the workload the CPU baseline is timed on")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from stereomatch_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    W, H, b, win = args.width, args.height, args.bands, args.window
+    Dg = args.disp_per_gpu
+    D = Dg * world
+    left, right, _ = synth.scene_pair(W, H, min(D, 256), n_bands=b)
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)
+    t_ref = torch.from_numpy(left.reshape(H, W * b)).to(dev)
+    t_mtc = torch.from_numpy(right.reshape(H, W * b)).to(dev)
+    keys = torch.empty((H, W), dtype=torch.int64, device=dev)
+    disp = torch.empty((H, W), dtype=torch.int32, device=dev)
+    best = torch.empty((H, W), dtype=torch.float32, device=dev)
+    p = capi.match_params(W, H, b, D, match_fn=1, match_interval=1, match_max=1000)
+    d_first = rank * Dg
+
+    def step():
+        ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, d_first, Dg,
+                               keys.data_ptr())
+        if world > 1:
+            dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+        ctx.keys_decode(keys.data_ptr(), W * H, disp.data_ptr(), best.data_ptr())
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.profile_begin(args.steps)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    n_prof, ms_a, ms_b = ctx.profile_end()
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    n_vox_gpu = W * H * Dg
+    n_vox = n_vox_gpu * world
+    value = n_vox * args.steps / dt / 1e9
+    ms_step = dt / args.steps * 1e3
+
+    if rank == 0:
+        # algorithmic bytes per launch: pass A writes the slab once and reads the
+        # images; pass B reads the slab once and writes one 8-byte key per pixel.
+        n_bt = 3 if p.match_interval else 2          # ref + (mn, mx) or ref + match
+        bytes_a = 4.0 * n_vox_gpu + n_bt * b * W * H
+        bytes_b = 4.0 * n_vox_gpu + 8.0 * W * H
+        bytes_fused = 8.0 * n_vox_gpu + 2.0 * b * W * H + 8.0 * W * H
+        ta, tb = ms_a / n_prof * 1e-3, ms_b / n_prof * 1e-3
+        traffic = {}
+        if os.path.exists(args.traffic_json):
+            with open(args.traffic_json) as f:
+                traffic = json.load(f)
+
+        def roof(name, nbytes, secs):
+            ach = nbytes / secs / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic.get(name), "avg_ms": round(secs * 1e3, 4),
+                    "algorithmic_bytes": int(nbytes)}
+        ka = roof("fused_rawbox_h_kernel", bytes_a, ta)
+        kb = roof("fused_boxv_wta_kernel", bytes_b, tb)
+        dominant = ka if ta >= tb else kb
+        fused = roof("fused pair (pass A + pass B)", bytes_fused, ta + tb)
+
+        out = {
+            "metric": "cost-volume throughput (G pixel*disparity/s)",
+            "value": round(value, 2), "unit": "G pixel*disparity/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, "
+                            "D=%d (%d levels per GPU%s)" % (
+                                win, win, W, H, b, D, Dg,
+                                ", int64-MIN RCCL all-reduce of keys" if world > 1 else ""),
+                "width": W, "height": H, "bands": b, "disp_total": D, "disp_per_gpu": Dg,
+                "window": win, "match_fn": "AD", "match_interval": 1, "match_max": 1000,
+                "parallelism": "disparity slabs x%d" % world},
+            "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+            "roofline_kernel": dominant["kernel"],
+            "roofline_fused": fused,
+            "kernels": [ka, kb],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(np, left, right, args, Dg, win)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+def cpu_baseline(np, left, right, args, D, win):
+    """The CPU oracle (a port of the reference's single-threaded CPU path, bit-identical to it on
+    the tsukuba anchors) on the top `cpu_rows` rows of the same image pair, one core."""
+    from oracle import oracle as O
+    rows = min(args.cpu_rows, left.shape[0])
+    l, r = np.ascontiguousarray(left[:rows]), np.ascontiguousarray(right[:rows])
+    h, w, b = l.shape
+    p = O.make_params(w, h, b, disp_min=0, disp_max=D - 1, match_fn=1, match_interval=1,
+                      match_max=1000, aggr_window_size=win)
+    O.lib()
+    t0 = time.perf_counter()
+    O.compute_correspondence(l, r, p)
+    dt = time.perf_counter() - t0
+    return {"value": round(w * h * D / dt / 1e9, 5), "unit": "G pixel*disparity/s", "cores": 1,
+            "kind": "port",
+            "sample": "top %d of %d rows of the same %dx%d D=%d pair (%.1f s of CPU work); "
+                      "oracle/sm_oracle.c, gcc -O2, single thread like the reference" % (
+                          rows, left.shape[0], w, left.shape[0], D, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -141,6 +141,14 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
                         size_t img_pitch, const smhip_match_params *p, int window,
                         int32_t *d_disp, float *d_best);
 
+/* ---- kernel timing (replaces the Timer of CudaUtilities.h:47-68 / profilingTimer) ----
+ * Between begin and end every smhip_fused_box_wta_keys() call brackets its two kernels with
+ * HIP events on the context's stream (no synchronisation is added).  smhip_profile_end()
+ * synchronises and returns the number of recorded calls and the summed milliseconds of pass A
+ * (raw cost + horizontal running sum) and pass B (vertical running sum + pad + WTA). */
+int smhip_profile_begin(smhip_ctx *ctx, int max_calls);
+int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_pass_b);
+
 #ifdef __cplusplus
 }
 #endif

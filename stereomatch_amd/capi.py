@@ -19,7 +19,7 @@ SYMBOLS = [
     "smhip_memcpy_d2h", "smhip_memcpy_d2d", "smhip_memcpy2d_h2d", "smhip_memcpy2d_d2h", "smhip_match_outside",
     "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_convolve_14641",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
-    "smhip_keys_decode", "smhip_fused_box_wta",
+    "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
 ]
 
 
@@ -94,6 +94,8 @@ def load():
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_keys_decode.argtypes = [vp, vp, sz, vp, vp]
     L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
+    L.smhip_profile_begin.argtypes = [vp, ci]
+    L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("smhip_last_error", "smhip_workspace_bytes", "smhip_match_outside"):
@@ -235,3 +237,12 @@ class Context:
     def fused_box_wta(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
         self._chk(self.L.smhip_fused_box_wta(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
                                              C.byref(p), window, _ptr(d_disp), _ptr(d_best)))
+
+    def profile_begin(self, max_calls):
+        self._chk(self.L.smhip_profile_begin(self.h, max_calls))
+
+    def profile_end(self):
+        """Returns (n_calls, total ms of pass A, total ms of pass B)."""
+        n, a, b = C.c_int(), C.c_float(), C.c_float()
+        self._chk(self.L.smhip_profile_end(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value

@@ -37,6 +37,8 @@ struct smhip_ctx {
     hipStream_t stream;
     void *ws[WS_COUNT];
     size_t ws_bytes[WS_COUNT];
+    hipEvent_t *ev;      // 3 events per profiled fused call
+    int ev_cap, ev_used; // in calls
 };
 
 namespace {
@@ -494,9 +496,13 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     float scale = (float)(1.0 / window);
     float outside = smhip_match_outside(p);
 
+    bool prof = ctx->ev && ctx->ev_used < ctx->ev_cap;
+    hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_used : nullptr;
+    if (prof) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
     long chains = (long)H * Dp;
     smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
         a, (float *)T, Dp, window, scale);
+    if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
     int tpb = CH < 64 ? 256 : CH * (256 / CH);
     int pix_per_blk = tpb / CH;
@@ -517,7 +523,55 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     if (n_chunks > 1)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
             kout, n_chunks, n_pix, (long long *)d_keys);
+    if (prof) {
+        HIP_TRY(hipEventRecord(ev[2], ctx->stream));
+        ctx->ev_used++;
+    }
     HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_profile_begin(smhip_ctx *ctx, int max_calls)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (max_calls < 1 || max_calls > 4096)
+        return fail(SMHIP_EINVAL, "max_calls must be in [1, 4096]");
+    if (ctx->ev)
+        return fail(SMHIP_EINVAL, "profiling already active");
+    ctx->ev = (hipEvent_t *)calloc((size_t)3 * max_calls, sizeof(hipEvent_t));
+    if (!ctx->ev)
+        return fail(SMHIP_ENOMEM, "out of host memory");
+    for (int i = 0; i < 3 * max_calls; i++)
+        HIP_TRY(hipEventCreate(&ctx->ev[i]));
+    ctx->ev_cap = max_calls;
+    ctx->ev_used = 0;
+    return SMHIP_OK;
+}
+
+int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_pass_b)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->ev)
+        return fail(SMHIP_EINVAL, "profiling not active");
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    float a = 0, b = 0;
+    for (int i = 0; i < ctx->ev_used; i++) {
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->ev[3 * i], ctx->ev[3 * i + 1]));
+        a += t;
+        HIP_TRY(hipEventElapsedTime(&t, ctx->ev[3 * i + 1], ctx->ev[3 * i + 2]));
+        b += t;
+    }
+    if (n_calls) *n_calls = ctx->ev_used;
+    if (ms_pass_a) *ms_pass_a = a;
+    if (ms_pass_b) *ms_pass_b = b;
+    for (int i = 0; i < 3 * ctx->ev_cap; i++)
+        hipEventDestroy(ctx->ev[i]);
+    free(ctx->ev);
+    ctx->ev = nullptr;
+    ctx->ev_cap = ctx->ev_used = 0;
     return SMHIP_OK;
 }
 

@@ -144,7 +144,7 @@ def test_diffusion(gpu_ctx, oracle, h, w, d, pad, beta):
     util.assert_bit_equal(got, oracle.diffusion_iter(c, 0.15, beta, c0), "diffusion")
 
 
-@pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (2, 5, 300)])
+@pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (3, 5, 300)])
 def test_wta(gpu_ctx, oracle, h, w, d):
     c = util.rand_dsi(h, w, d, 50)
     c[0, 0, :] = 5.0
