@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--window", type=int, default=9)
     ap.add_argument("--bands", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=135,
+    ap.add_argument("--cpu-rows", type=int, default=1080,
                     help="rows of the workload the CPU baseline is timed on")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")

@@ -1,6 +1,7 @@
 // smhip_api.hip -- the C-ABI of include/smhip.h: argument checks, workspace, launches.
 #include "../../include/smhip.h"
 #include "smhip_kernels.h"
+#include "smhip_fused.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -499,27 +500,53 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     bool prof = ctx->ev && ctx->ev_used < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_used : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    long chains = (long)H * Dp;
-    smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
-        a, (float *)T, Dp, window, scale);
+    const bool tuned = (Dp % 64 == 0);
+    if (tuned && p->n_bands == 1) {
+        smk::FusedA fa;
+        fa.rn = a.rmn; fa.rx = a.rmx ? a.rmx : a.rmn;
+        fa.mn = a.mmn; fa.mx = a.mmx ? a.mmx : a.mmn;
+        fa.pitch = img_pitch; fa.W = W; fa.H = H; fa.D = d_count;
+        fa.disp0 = a.disp0; fa.dstep = a.dstep; fa.cutoff = a.cutoff; fa.outside = a.outside;
+        int tpa = Dp < 256 ? Dp : 256;
+        dim3 ga(H, Dp / tpa);
+        size_t lds = (size_t)W * 2 * sizeof(uint16_t);
+        if (lds > 150 * 1024)
+            return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
+#define LAUNCH_A(WIN, SD) smk::fused_rawbox_h_lds_kernel<WIN, SD><<<ga, tpa, lds, ctx->stream>>>( \
+        fa, (float *)T, Dp, window, scale)
+        if (window == 9) { if (a.sd) LAUNCH_A(9, true); else LAUNCH_A(9, false); }
+        else             { if (a.sd) LAUNCH_A(0, true); else LAUNCH_A(0, false); }
+#undef LAUNCH_A
+    } else {
+        long chains = (long)H * Dp;
+        smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
+            a, (float *)T, Dp, window, scale);
+    }
     if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
     int tpb = CH < 64 ? 256 : CH * (256 / CH);
     int pix_per_blk = tpb / CH;
     dim3 grid((W + pix_per_blk - 1) / pix_per_blk, n_chunks);
+    if (tuned) {
+#define LAUNCH_BT(WIN) smk::fused_boxv_wta_dpp_kernel<WIN><<<grid, tpb, 0, ctx->stream>>>(          \
+        (const float *)T, W, H, Dp, d_count, CH, window, scale, a.disp0, a.dstep, outside, d_first, \
+        kout, n_pix)
+        if (window == 9) LAUNCH_BT(9); else LAUNCH_BT(0);
+#undef LAUNCH_BT
+    } else {
 #define LAUNCH_B(SEG)                                                                          \
     smk::fused_boxv_wta_kernel<SEG><<<grid, tpb, 0, ctx->stream>>>(                            \
         (const float *)T, W, H, Dp, d_count, CH, CH, window, scale, a.disp0, a.dstep, outside, \
         d_first, kout, n_pix)
-    switch (CH < 64 ? CH : 64) {
-    case 2: LAUNCH_B(2); break;
-    case 4: LAUNCH_B(4); break;
-    case 8: LAUNCH_B(8); break;
-    case 16: LAUNCH_B(16); break;
-    case 32: LAUNCH_B(32); break;
-    default: LAUNCH_B(64); break;
-    }
+        switch (CH) {
+        case 2: LAUNCH_B(2); break;
+        case 4: LAUNCH_B(4); break;
+        case 8: LAUNCH_B(8); break;
+        case 16: LAUNCH_B(16); break;
+        default: LAUNCH_B(32); break;
+        }
 #undef LAUNCH_B
+    }
     if (n_chunks > 1)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
             kout, n_chunks, n_pix, (long long *)d_keys);
