@@ -2,6 +2,7 @@
 #include "../../include/smhip.h"
 #include "smhip_kernels.h"
 #include "smhip_fused.h"
+#include "smhip_fused_b.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -471,9 +472,12 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         Dp = 2;
         while (Dp < d_count) Dp <<= 1;
         CH = Dp;
+    } else if (d_count <= 64) {
+        Dp = CH = 64;
+    } else if (d_count <= 128) {
+        Dp = CH = 128;
     } else if (d_count <= 256) {
-        Dp = (d_count + 63) / 64 * 64;
-        CH = Dp;
+        Dp = CH = 256;
     } else {
         Dp = (d_count + 255) / 256 * 256;
         CH = 256;
@@ -484,8 +488,13 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
     if (rc) return rc;
+    // T[y][x][Dp]; image rows of T are padded by 64 floats so that the H concurrent row
+    // streams of pass A do not all sit on the same 128 KB-aligned offsets
+    size_t tpad = 64;
+    if (const char *e = getenv("SMHIP_TPAD")) tpad = (size_t)atol(e);
+    size_t trow = (size_t)W * Dp + tpad;
     void *T = nullptr;
-    rc = ws_get(ctx, WS_TMP, n_pix * Dp * sizeof(float), &T);
+    rc = ws_get(ctx, WS_TMP, trow * H * sizeof(float), &T);
     if (rc) return rc;
     long long *kout = (long long *)d_keys;
     if (n_chunks > 1) {
@@ -513,14 +522,14 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
 #define LAUNCH_A(WIN, SD) smk::fused_rawbox_h_lds_kernel<WIN, SD><<<ga, tpa, lds, ctx->stream>>>( \
-        fa, (float *)T, Dp, window, scale)
+        fa, (float *)T, trow, Dp, window, scale)
         if (window == 9) { if (a.sd) LAUNCH_A(9, true); else LAUNCH_A(9, false); }
         else             { if (a.sd) LAUNCH_A(0, true); else LAUNCH_A(0, false); }
 #undef LAUNCH_A
     } else {
         long chains = (long)H * Dp;
         smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
-            a, (float *)T, Dp, window, scale);
+            a, (float *)T, trow, Dp, window, scale);
     }
     if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
@@ -528,15 +537,26 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     int pix_per_blk = tpb / CH;
     dim3 grid((W + pix_per_blk - 1) / pix_per_blk, n_chunks);
     if (tuned) {
-#define LAUNCH_BT(WIN) smk::fused_boxv_wta_dpp_kernel<WIN><<<grid, tpb, 0, ctx->stream>>>(          \
-        (const float *)T, W, H, Dp, d_count, CH, window, scale, a.disp0, a.dstep, outside, d_first, \
-        kout, n_pix)
-        if (window == 9) LAUNCH_BT(9); else LAUNCH_BT(0);
+        // one wave per pixel column and chunk, 4 columns per block, columns dealt per XCD
+        const int wpb = 4;
+        int x_per_xcd = (W + 7) / 8;
+        dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), n_chunks);
+#define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, 0, ctx->stream>>>( \
+        (const float *)T, trow, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside, d_first,   \
+        x_per_xcd, kout, n_pix)
+#define LAUNCH_BW(WIN)                                 \
+        switch (CH / 64) {                             \
+        case 1: LAUNCH_BT(WIN, 1); break;              \
+        case 2: LAUNCH_BT(WIN, 2); break;              \
+        default: LAUNCH_BT(WIN, 4); break;             \
+        }
+        if (window == 9) { LAUNCH_BW(9) } else { LAUNCH_BW(0) }
+#undef LAUNCH_BW
 #undef LAUNCH_BT
     } else {
 #define LAUNCH_B(SEG)                                                                          \
     smk::fused_boxv_wta_kernel<SEG><<<grid, tpb, 0, ctx->stream>>>(                            \
-        (const float *)T, W, H, Dp, d_count, CH, CH, window, scale, a.disp0, a.dstep, outside, \
+        (const float *)T, trow, W, H, Dp, d_count, CH, CH, window, scale, a.disp0, a.dstep, outside, \
         d_first, kout, n_pix)
         switch (CH) {
         case 2: LAUNCH_B(2); break;

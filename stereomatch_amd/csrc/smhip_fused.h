@@ -52,7 +52,8 @@ __device__ __forceinline__ int cost1(const uint16_t *Rl, const uint16_t *Ml, int
 
 template <int WIN, bool SD>
 __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float *__restrict__ T,
-                                                                 int Dp, int win, float scale)
+                                                                 size_t trow, int Dp, int win,
+                                                                 float scale)
 {
     extern __shared__ uint16_t lds_a[];
     const int W = a.W;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
         return;
     const int disp = a.disp0 + k * a.dstep;
     const int cutoff = a.cutoff, outside = a.outside;
-    float *t = T + ((size_t)y * W) * Dp + k;
+    float *t = T + (size_t)y * trow + k;   // trow = floats per image row of T (>= W*Dp)
     const int w = WIN ? WIN : win;
     const int pr = w / 2, pl = pr - w;
 
@@ -140,18 +141,33 @@ __device__ __forceinline__ int wave_min_i32(int v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-constexpr int BLK = 8;   // rows per block of pass B
+// One step of pass B: running-sum value -> PadCosts -> wave argmin -> key.
+__device__ __forceinline__ long long wta_step(float acc, bool padded, float outside, bool live,
+                                              int dbase)
+{
+    float v = padded ? outside : acc;
+    int s = live ? ordered_bits(v) : 0x7FFFFFFF;
+    int m = wave_min_i32(s);
+    unsigned long long eq = __builtin_amdgcn_ballot_w64(s == m);
+    return make_key(m, dbase + (int)__builtin_ctzll(eq));
+}
 
-template <int WIN>
+// WIN > 0: the window is a template parameter, rows are processed in blocks of WIN so that
+// the row leaving the window at step r of a block is the row that entered at step r of the
+// previous block (kept in registers: every element of T is loaded exactly once).
+// WIN == 0: generic window, blocks of 8 rows, the leaving row is re-read (L2 hit).
+// WPP = waves per pixel (1, 2, 3 or 4); blockDim.x = 64*WPP*PPW.
+template <int WIN, int WPP>
 __global__ __launch_bounds__(256) void fused_boxv_wta_dpp_kernel(
-    const float *__restrict__ T, int W, int H, int Dp, int D, int CH, int win, float scale,
+    const float *__restrict__ T, size_t trow, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, long long *__restrict__ keys,
     size_t keys_chunk_stride)
 {
+    constexpr int BLK = WIN ? WIN : 8;
+    constexpr int CH = 64 * WPP;
     __shared__ long long ring[2][BLK][4];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
-    const int wpp = CH >> 6;                          // waves per pixel
     const int ppw = blockDim.x / CH;                  // pixels per workgroup
     const int pix = tid / CH, kloc = tid - pix * CH;
     const int x = blockIdx.x * ppw + pix;
@@ -160,8 +176,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_dpp_kernel(
     const bool live = (x < W) && (k < D);
     const int xs = x < W ? x : W - 1;
     const int ks = k < D ? k : D - 1;
-    const float *t = T + (size_t)xs * Dp + ks;
-    const size_t stride = (size_t)W * Dp;
+    const unsigned j = (unsigned)xs * (unsigned)Dp + (unsigned)ks;   // lane offset inside a row of T
+    const size_t stride = trow;
     const int w = WIN ? WIN : win;
     const int pr = w / 2, pl = pr - w;
     const int disp = disp0 + ks * dstep;
@@ -169,59 +185,92 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_dpp_kernel(
     long long *kout = keys + (size_t)chunk * keys_chunk_stride;
     const int dbase = d_first + chunk * CH + (kloc & ~63);   // level of lane 0 of this wave
 
+    // row index is wave-uniform: scalar base + 32-bit lane offset
+    auto ld = [&](int row) -> float { return (T + (size_t)clampi(row, H) * stride)[j]; };
+
     float acc = 0;
     for (int i = pl + 1; i <= pr; i++)
-        acc += scale * t[stride * clampi(i, H)];
+        acc += scale * ld(i);
 
-    float nw[2][BLK], od[2][BLK];
+    auto emit = [&](long long key, int y, int r, int buf) {
+        if (WPP == 1) {
+            if (lane == 0 && y < H && x < W)
+                kout[(size_t)y * W + x] = key;
+        } else if (lane == 0) {
+            ring[buf][r][wv] = key;
+        }
+    };
+    auto combine = [&](int yb, int buf) {
+        if (WPP > 1) {
+            __syncthreads();
+            if (tid < BLK * ppw) {
+                int r = tid / ppw, p = tid - r * ppw;
+                long long m = ring[buf][r][p * WPP];
 #pragma unroll
-    for (int r = 0; r < BLK; r++) {
-        nw[0][r] = t[stride * clampi(r + pr, H)];
-        od[0][r] = t[stride * clampi(r + pl, H)];
-    }
-    int buf = 0;
-    for (int y0 = 0; y0 < H; y0 += 2 * BLK) {
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int yb = y0 + half * BLK;
-            if (yb < H) {
-                // issue the next block's loads before consuming this one
-#pragma unroll
-                for (int r = 0; r < BLK; r++) {
-                    nw[half ^ 1][r] = t[stride * clampi(yb + BLK + r + pr, H)];
-                    od[half ^ 1][r] = t[stride * clampi(yb + BLK + r + pl, H)];
+                for (int q = 1; q < WPP; q++) {
+                    long long o = ring[buf][r][p * WPP + q];
+                    m = o < m ? o : m;
                 }
+                int xx = blockIdx.x * ppw + p;
+                if (xx < W && yb + r < H)
+                    kout[(size_t)(yb + r) * W + xx] = m;
+            }
+        }
+    };
+
+    if (WIN) {
+        float b0[BLK], b1[BLK], b2[BLK];
 #pragma unroll
-                for (int r = 0; r < BLK; r++) {
-                    const int y = yb + r;
-                    if (y > 0)
+        for (int r = 0; r < BLK; r++) {
+            b0[r] = ld(r + pl);
+            b1[r] = ld(r + pr);
+        }
+        b0[0] = b1[0];   // step y = 0 adds scale*(-a + a) = +0: the first value is the plain window sum
+        int buf = 0;
+        auto block = [&](float(&prv)[BLK], float(&cur)[BLK], float(&nxt)[BLK], int yb) {
+#pragma unroll
+            for (int r = 0; r < BLK; r++)
+                nxt[r] = ld(yb + BLK + r + pr);
+#pragma unroll
+            for (int r = 0; r < BLK; r++) {
+                acc = acc + scale * (-prv[r] + cur[r]);
+                emit(wta_step(acc, padded, outside, live, dbase), yb + r, r, buf);
+            }
+            combine(yb, buf);
+            buf ^= 1;
+        };
+        for (int yb = 0; yb < H; yb += 3 * BLK) {
+            block(b0, b1, b2, yb);
+            if (yb + BLK < H)
+                block(b1, b2, b0, yb + BLK);
+            if (yb + 2 * BLK < H)
+                block(b2, b0, b1, yb + 2 * BLK);
+        }
+    } else {
+        float nw[2][BLK], od[2][BLK];
+#pragma unroll
+        for (int r = 0; r < BLK; r++) {
+            nw[0][r] = ld(r + pr);
+            od[0][r] = ld(r + pl);
+        }
+        od[0][0] = nw[0][0];
+        int buf = 0;
+        for (int y0 = 0; y0 < H; y0 += 2 * BLK) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int yb = y0 + half * BLK;
+                if (yb < H) {
+#pragma unroll
+                    for (int r = 0; r < BLK; r++) {
+                        nw[half ^ 1][r] = ld(yb + BLK + r + pr);
+                        od[half ^ 1][r] = ld(yb + BLK + r + pl);
+                    }
+#pragma unroll
+                    for (int r = 0; r < BLK; r++) {
                         acc = acc + scale * (-od[half][r] + nw[half][r]);
-                    float v = padded ? outside : acc;
-                    int s = live ? ordered_bits(v) : 0x7FFFFFFF;
-                    int m = wave_min_i32(s);
-                    unsigned long long eq = __builtin_amdgcn_ballot_w64(s == m);
-                    int d = dbase + (int)__builtin_ctzll(eq);
-                    long long key = make_key(m, d);
-                    if (wpp == 1) {
-                        if (lane == 0 && y < H && x < W)
-                            kout[(size_t)y * W + x] = key;
-                    } else if (lane == 0) {
-                        ring[buf][r][wv] = key;
+                        emit(wta_step(acc, padded, outside, live, dbase), yb + r, r, buf);
                     }
-                }
-                if (wpp > 1) {
-                    __syncthreads();
-                    if (tid < BLK * ppw) {
-                        int r = tid / ppw, p = tid - r * ppw;
-                        long long m = ring[buf][r][p * wpp];
-                        for (int q = 1; q < wpp; q++) {
-                            long long o = ring[buf][r][p * wpp + q];
-                            m = o < m ? o : m;
-                        }
-                        int xx = blockIdx.x * ppw + p;
-                        if (xx < W && yb + r < H)
-                            kout[(size_t)(yb + r) * W + xx] = m;
-                    }
+                    combine(yb, buf);
                     buf ^= 1;
                 }
             }

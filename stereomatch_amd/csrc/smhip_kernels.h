@@ -333,7 +333,7 @@ __global__ void keys_min_kernel(const long long *part, int n_part, size_t n, lon
 // One thread per (y, k) chain, k on lanes.  The raw costs entering and leaving the window
 // are recomputed from the image lines (integers, exact in float), so the raw DSI is never
 // written: HBM traffic = one write of T.
-__global__ void fused_rawbox_h_kernel(RawArgs a, float *T, int Dp, int w, float scale)
+__global__ void fused_rawbox_h_kernel(RawArgs a, float *T, size_t trow, int Dp, int w, float scale)
 {
     long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (long)a.H * Dp)
@@ -346,7 +346,7 @@ __global__ void fused_rawbox_h_kernel(RawArgs a, float *T, int Dp, int w, float 
     const uint8_t *mmn = a.mmn + ro, *mmx = a.mmx ? a.mmx + ro : nullptr;
     int W = a.W;
     int pr = w / 2, pl = pr - w;
-    float *t = T + ((size_t)y * W) * Dp + k;
+    float *t = T + (size_t)y * trow + k;
     float acc = 0;
     for (int i = pl + 1; i <= pr; i++)
         acc += scale * (float)raw_cost(a, rmn, rmx, mmn, mmx, clampi(i, W), k);
@@ -367,7 +367,7 @@ __global__ void fused_rawbox_h_kernel(RawArgs a, float *T, int Dp, int w, float 
 constexpr int RING = 16;
 
 template <int SEG>   // SEG = min(CH, 64)
-__global__ void fused_boxv_wta_kernel(const float *T, int W, int H, int Dp, int D, int CH,
+__global__ void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H, int Dp, int D, int CH,
                                       int chunk_base_stride, int w, float scale,
                                       int disp0, int dstep, float outside, int d_first,
                                       long long *keys, size_t keys_chunk_stride)
@@ -384,7 +384,7 @@ __global__ void fused_boxv_wta_kernel(const float *T, int W, int H, int Dp, int 
     int xs = x < W ? x : W - 1;
     int ks = k < D ? k : D - 1;
     const float *t = T + (size_t)xs * Dp + ks;
-    size_t stride = (size_t)W * Dp;
+    size_t stride = trow;
     int pr = w / 2, pl = pr - w;
     int disp = disp0 + ks * dstep;
     bool padded = (xs + disp < 0) || (xs + disp >= W);   // PadLine, StcRawCosts.cpp:451-456
