@@ -70,7 +70,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
     t_ref = torch.from_numpy(left.reshape(H, W * b)).to(dev)
     t_mtc = torch.from_numpy(right.reshape(H, W * b)).to(dev)
-    keys = torch.empty((H, W), dtype=torch.int64, device=dev)
+    keys = torch.empty((W, H), dtype=torch.int64, device=dev)   # column-major key image
     disp = torch.empty((H, W), dtype=torch.int32, device=dev)
     best = torch.empty((H, W), dtype=torch.float32, device=dev)
     p = capi.match_params(W, H, b, D, match_fn=1, match_interval=1, match_max=1000)
@@ -81,7 +81,7 @@ def main():
                                keys.data_ptr())
         if world > 1:
             dist.all_reduce(keys, op=dist.ReduceOp.MIN)
-        ctx.keys_decode(keys.data_ptr(), W * H, disp.data_ptr(), best.data_ptr())
+        ctx.keys_decode(keys.data_ptr(), W, H, disp.data_ptr(), best.data_ptr())
 
     def fence():
         if world > 1:

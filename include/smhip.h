@@ -129,12 +129,14 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
  * emits one signed 64-bit key per pixel:
  *     key = (ordered_bits(best cost) << 32) | d        (d = global level index)
  * ordered_bits() maps float order to int32 order, so min(key) over slabs (e.g. an
- * int64 MIN all-reduce across GPUs) is OptWTA's winner with its lowest-d tie break. */
+ * int64 MIN all-reduce across GPUs) is OptWTA's winner with its lowest-d tie break.
+ * d_keys holds width*height keys, COLUMN-MAJOR: the key of pixel (x, y) is d_keys[x*height + y]
+ * (each wave owns a pixel column and stores runs of consecutive rows). */
 int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                              size_t img_pitch, const smhip_match_params *p, int window,
                              int d_first, int d_count, int64_t *d_keys);
-/* keys -> disparity and best cost (either may be NULL); n = W*H */
-int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, size_t n,
+/* column-major keys -> row-major disparity and best cost images (either may be NULL) */
+int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int height,
                       int32_t *d_disp, float *d_best);
 /* convenience: all D levels on this device, then decode */
 int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,

@@ -92,7 +92,7 @@ def load():
     L.smhip_pad_costs.argtypes = [vp, vp, sz, pp]
     L.smhip_wta.argtypes = [vp, vp, ci, ci, ci, sz, vp, vp]
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
-    L.smhip_keys_decode.argtypes = [vp, vp, sz, vp, vp]
+    L.smhip_keys_decode.argtypes = [vp, vp, ci, ci, vp, vp]
     L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
@@ -231,8 +231,10 @@ class Context:
                                                   C.byref(p), window, d_first, d_count,
                                                   _ptr(d_keys)))
 
-    def keys_decode(self, d_keys, n, d_disp, d_best):
-        self._chk(self.L.smhip_keys_decode(self.h, _ptr(d_keys), n, _ptr(d_disp), _ptr(d_best)))
+    def keys_decode(self, d_keys, width, height, d_disp, d_best):
+        """d_keys: width*height int64, column-major (pixel (x, y) at x*height + y)."""
+        self._chk(self.L.smhip_keys_decode(self.h, _ptr(d_keys), width, height, _ptr(d_disp),
+                                           _ptr(d_best)))
 
     def fused_box_wta(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
         self._chk(self.L.smhip_fused_box_wta(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,

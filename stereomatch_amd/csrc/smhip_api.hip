@@ -437,14 +437,16 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
     return SMHIP_OK;
 }
 
-int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, size_t n, int32_t *d_disp, float *d_best)
+int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int height,
+                      int32_t *d_disp, float *d_best)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
-    if (!d_keys || n == 0 || (!d_disp && !d_best))
+    if (!d_keys || width < 1 || height < 1 || (!d_disp && !d_best))
         return fail(SMHIP_EINVAL, "bad decode request");
-    smk::keys_decode_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(
-        (const long long *)d_keys, n, d_disp, d_best);
+    dim3 grid((width + 31) / 32, (height + 31) / 32);
+    smk::keys_decode_t_kernel<<<grid, 256, 0, ctx->stream>>>((const long long *)d_keys, width, height,
+                                                            d_disp, d_best);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -466,7 +468,8 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     if (window < 1 || window - window / 2 >= W || window - window / 2 >= H)
         return fail(SMHIP_EINVAL, "BoxFilter: window %d unusable for %dx%d", window, W, H);
 
-    // padded slab width: power of two below 64, else a multiple of 64 (of 256 above 256)
+    // padded slab width Dp: a power of two below 64 (narrow kernels), else 64 / 128 / 256 with
+    // 1 / 2 / 4 levels per lane, else chunks of 256 levels
     int Dp, CH;
     if (d_count <= 32) {
         Dp = 2;
@@ -484,17 +487,22 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     }
     int n_chunks = Dp / CH;
     size_t n_pix = (size_t)W * H;
+    const bool wide = (Dp % 64 == 0);
+    const bool tuned_a = wide && p->n_bands == 1;
+    // banded slab layout (smhip_fused.h) only when both passes are the tuned kernels
+    int tyshift = tuned_a ? 5 : 0;
+    if (const char *e = getenv("SMHIP_TYSHIFT")) { if (tuned_a) tyshift = atoi(e); }
+    if (tyshift < 0 || tyshift > 8)
+        return fail(SMHIP_EINVAL, "bad SMHIP_TYSHIFT");
+    size_t bands = ((size_t)H + (1u << tyshift) - 1) >> tyshift;
+    size_t trow = (size_t)W * Dp;                       // floats per image row of T
+    size_t t_elems = (bands << tyshift) * trow;
 
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
     if (rc) return rc;
-    // T[y][x][Dp]; image rows of T are padded by 64 floats so that the H concurrent row
-    // streams of pass A do not all sit on the same 128 KB-aligned offsets
-    size_t tpad = 64;
-    if (const char *e = getenv("SMHIP_TPAD")) tpad = (size_t)atol(e);
-    size_t trow = (size_t)W * Dp + tpad;
     void *T = nullptr;
-    rc = ws_get(ctx, WS_TMP, trow * H * sizeof(float), &T);
+    rc = ws_get(ctx, WS_TMP, t_elems * sizeof(float), &T);
     if (rc) return rc;
     long long *kout = (long long *)d_keys;
     if (n_chunks > 1) {
@@ -509,8 +517,7 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     bool prof = ctx->ev && ctx->ev_used < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_used : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
-    const bool tuned = (Dp % 64 == 0);
-    if (tuned && p->n_bands == 1) {
+    if (tuned_a) {
         smk::FusedA fa;
         fa.rn = a.rmn; fa.rx = a.rmx ? a.rmx : a.rmn;
         fa.mn = a.mmn; fa.mx = a.mmx ? a.mmx : a.mmn;
@@ -522,7 +529,7 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
 #define LAUNCH_A(WIN, SD) smk::fused_rawbox_h_lds_kernel<WIN, SD><<<ga, tpa, lds, ctx->stream>>>( \
-        fa, (float *)T, trow, Dp, window, scale)
+        fa, (float *)T, tyshift, Dp, window, scale)
         if (window == 9) { if (a.sd) LAUNCH_A(9, true); else LAUNCH_A(9, false); }
         else             { if (a.sd) LAUNCH_A(0, true); else LAUNCH_A(0, false); }
 #undef LAUNCH_A
@@ -533,17 +540,14 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     }
     if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
-    int tpb = CH < 64 ? 256 : CH * (256 / CH);
-    int pix_per_blk = tpb / CH;
-    dim3 grid((W + pix_per_blk - 1) / pix_per_blk, n_chunks);
-    if (tuned) {
+    if (wide) {
         // one wave per pixel column and chunk, 4 columns per block, columns dealt per XCD
         const int wpb = 4;
         int x_per_xcd = (W + 7) / 8;
         dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), n_chunks);
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, 0, ctx->stream>>>( \
-        (const float *)T, trow, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside, d_first,   \
-        x_per_xcd, kout, n_pix)
+        (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
+        d_first, x_per_xcd, kout, n_pix)
 #define LAUNCH_BW(WIN)                                 \
         switch (CH / 64) {                             \
         case 1: LAUNCH_BT(WIN, 1); break;              \
@@ -554,10 +558,11 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
 #undef LAUNCH_BW
 #undef LAUNCH_BT
     } else {
-#define LAUNCH_B(SEG)                                                                          \
-    smk::fused_boxv_wta_kernel<SEG><<<grid, tpb, 0, ctx->stream>>>(                            \
-        (const float *)T, trow, W, H, Dp, d_count, CH, CH, window, scale, a.disp0, a.dstep, outside, \
-        d_first, kout, n_pix)
+        int pix_per_blk = 256 / CH;
+        unsigned gx = (unsigned)((W + pix_per_blk - 1) / pix_per_blk);
+#define LAUNCH_B(SEG)                                                                        \
+    smk::fused_boxv_wta_kernel<SEG><<<gx, 256, 0, ctx->stream>>>(                            \
+        (const float *)T, trow, W, H, d_count, window, scale, a.disp0, a.dstep, outside, d_first, kout)
         switch (CH) {
         case 2: LAUNCH_B(2); break;
         case 4: LAUNCH_B(4); break;
@@ -641,7 +646,7 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
     int64_t *keys = (int64_t *)kws + n_pix * (size_t)n_chunks;
     rc = smhip_fused_box_wta_keys(ctx, d_ref, d_mtc, img_pitch, p, window, 0, d_count, keys);
     if (rc) return rc;
-    return smhip_keys_decode(ctx, keys, n_pix, d_disp, d_best);
+    return smhip_keys_decode(ctx, keys, p->width, p->height, d_disp, d_best);
 }
 
 }  // extern "C"

@@ -304,16 +304,6 @@ __global__ void wta_thread_kernel(const float *cost, int W, int H, int D, size_t
     if (best) best[p] = bc;
 }
 
-__global__ void keys_decode_kernel(const long long *keys, size_t n, int32_t *disp, float *best)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    long long k = keys[i];
-    if (disp) disp[i] = (int32_t)(k & 0xFFFFFFFFll);
-    if (best) best[i] = unordered_bits((int)(k >> 32));
-}
-
 __global__ void keys_min_kernel(const long long *part, int n_part, size_t n, long long *out)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -359,37 +349,27 @@ __global__ void fused_rawbox_h_kernel(RawArgs a, float *T, size_t trow, int Dp, 
     }
 }
 
-// Pass B: vertical running sum over T + PadCosts + WTA -> one key per pixel (and chunk).
-// Thread j = (pixel, k) with k on lanes; CH = lanes per pixel in this block (power of two
-// below 64, or a multiple of 64 up to 256).  Each step the lanes of a pixel min-reduce
-// (ordered cost, d); for CH > 64 the per-wave winners are combined through LDS every
-// RING steps.
-constexpr int RING = 16;
-
-template <int SEG>   // SEG = min(CH, 64)
-__global__ void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H, int Dp, int D, int CH,
-                                      int chunk_base_stride, int w, float scale,
-                                      int disp0, int dstep, float outside, int d_first,
-                                      long long *keys, size_t keys_chunk_stride)
+// Pass B for narrow slabs (Dp a power of two below 64): vertical running sum over T +
+// PadCosts + WTA.  Thread = (pixel column, level), the SEG = Dp lanes of a pixel are one
+// aligned lane segment of a wave and min-reduce (ordered cost, d) with shuffles.  Keys are
+// written column-major (pixel (x,y) at x*H + y), like the wide-slab kernel of smhip_fused_b.h.
+template <int SEG>
+__global__ void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H, int D, int w,
+                                      float scale, int disp0, int dstep, float outside,
+                                      int d_first, long long *keys)
 {
-    __shared__ long long ring[RING][4];
     int tid = threadIdx.x;
-    int lane = tid & 63, wv = tid >> 6;
-    int pix_per_blk = blockDim.x / CH;
-    int pl_local = tid / CH, kloc = tid - pl_local * CH;
+    int pix_per_blk = blockDim.x / SEG;
+    int pl_local = tid / SEG, k = tid - pl_local * SEG;
     int x = blockIdx.x * pix_per_blk + pl_local;
-    int chunk = blockIdx.y;
-    int k = chunk * chunk_base_stride + kloc;        // level index within the slab
     bool live = (x < W) && (k < D);
     int xs = x < W ? x : W - 1;
     int ks = k < D ? k : D - 1;
-    const float *t = T + (size_t)xs * Dp + ks;
+    const float *t = T + (size_t)xs * SEG + ks;
     size_t stride = trow;
     int pr = w / 2, pl = pr - w;
     int disp = disp0 + ks * dstep;
     bool padded = (xs + disp < 0) || (xs + disp >= W);   // PadLine, StcRawCosts.cpp:451-456
-    long long *kout = keys + (size_t)chunk * keys_chunk_stride;
-    int waves_per_pix = CH >> 6;                      // 0 when CH < 64
 
     float acc = 0;
     for (int i = pl + 1; i <= pr; i++)
@@ -404,34 +384,8 @@ __global__ void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H,
         int s = live ? ordered_bits(v) : 0x7FFFFFFF;
         int d = live ? d_first + k : 0x7FFFFFFF;
         seg_min<SEG>(s, d);
-        if (SEG < 64) {
-            if (kloc == 0 && x < W)
-                kout[(size_t)y * W + x] = make_key(s, d);
-        } else if (waves_per_pix == 1) {
-            if (lane == 0 && x < W)
-                kout[(size_t)y * W + x] = make_key(s, d);
-        } else {
-            int slot = y & (RING - 1);
-            if (lane == 0)
-                ring[slot][wv] = make_key(s, d);
-            if (slot == RING - 1 || y == H - 1) {
-                __syncthreads();
-                int n = slot + 1;
-                // thread (r, p): step r of this batch, pixel p of the block
-                if (tid < n * pix_per_blk) {
-                    int r = tid / pix_per_blk, p = tid - r * pix_per_blk;
-                    long long m = ring[r][p * waves_per_pix];
-                    for (int q = 1; q < waves_per_pix; q++) {
-                        long long o = ring[r][p * waves_per_pix + q];
-                        m = o < m ? o : m;
-                    }
-                    int xx = blockIdx.x * pix_per_blk + p;
-                    if (xx < W)
-                        kout[(size_t)(y - slot + r) * W + xx] = m;
-                }
-                __syncthreads();
-            }
-        }
+        if (k == 0 && x < W)
+            keys[(size_t)x * H + y] = make_key(s, d);
     }
 }
 

@@ -88,11 +88,11 @@ def test_disparity_slabs_merge_to_full_result(gpu_ctx, oracle, D, slabs):
     bounds = [D * i // slabs for i in range(slabs + 1)]
     for i in range(slabs):
         gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, w, p, 9, bounds[i], bounds[i + 1] - bounds[i], keys)
-        k = gpu_ctx.download(keys, (h, w), np.int64)
+        k = gpu_ctx.download(keys, (w, h), np.int64)
         merged = k if merged is None else np.minimum(merged, k)
     dk = gpu_ctx.upload(merged)
     disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
-    gpu_ctx.keys_decode(dk, w * h, disp, best)
+    gpu_ctx.keys_decode(dk, w, h, disp, best)
     util.assert_bit_equal(gpu_ctx.download(disp, (h, w), np.int32), odisp, "merged disparity")
     util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), obest, "merged best cost")
 
@@ -119,6 +119,6 @@ def test_full_size_properties(gpu_ctx):
     merged = None
     for d0 in (0, 128):
         gpu_ctx.fused_box_wta_keys(m.d_ref, m.d_mtc, w, p, 9, d0, 128, keys)
-        k = gpu_ctx.download(keys, (h, w), np.int64)
+        k = gpu_ctx.download(keys, (w, h), np.int64)
         merged = k if merged is None else np.minimum(merged, k)
-    assert np.array_equal((merged & 0xFFFFFFFF).astype(np.int32), disp)
+    assert np.array_equal((merged & 0xFFFFFFFF).astype(np.int32).T, disp)   # keys are column-major
