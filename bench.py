@@ -48,7 +48,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from stereomatch_amd import capi, synth
+    from stereomatch_amd import capi, sharding, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,7 +80,7 @@ def main():
         ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, d_first, Dg,
                                keys.data_ptr())
         if world > 1:
-            dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+            sharding.all_reduce_min_keys(keys)          # the one exchange step (RCCL over xGMI)
         ctx.keys_decode(keys.data_ptr(), W, H, disp.data_ptr(), best.data_ptr())
 
     def fence():

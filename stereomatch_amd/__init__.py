@@ -4,4 +4,4 @@ Only what the hot path needs: `csrc/` (HIP kernels + the C-ABI of include/smhip.
 into lib/libsmhip.so), `capi` (ctypes binding), `pnm` (PGM/PPM I/O with the reference's
 band layout) and `synth` (deterministic synthetic stereo pairs for the benchmarks).
 """
-from . import capi, pnm, synth  # noqa: F401
+from . import capi, pnm, sharding, synth  # noqa: F401

@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: slab partition, key order, and a world_size-2 gloo MIN all-reduce
+that must reproduce the single-process WTA of the oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import util
+from stereomatch_amd import sharding, synth
+
+
+def test_slab_bounds_cover_every_level_once():
+    for D in (2, 16, 100, 256, 1024):
+        for world in (1, 2, 3, 8):
+            if world > D:
+                continue
+            seen = []
+            for r in range(world):
+                d0, n = sharding.slab_bounds(D, world, r)
+                assert n >= D // world
+                seen += list(range(d0, d0 + n))
+            assert seen == list(range(D))
+    with pytest.raises(ValueError):
+        sharding.slab_bounds(4, 8, 0)
+
+
+def test_key_order_matches_float_order_and_tie_break():
+    c = np.array([0.0, -0.0, 1.5, -2.25, 3e-39, -3e-39, 260100.0, 1e30, -1e30], np.float32)
+    s = sharding.ordered_bits(c)
+    for i in range(len(c)):
+        for j in range(len(c)):
+            assert (c[i] < c[j]) == (s[i] < s[j]), (c[i], c[j])
+    k = sharding.encode_keys(np.float32([5.0, 5.0, 7.0]), [9, 3, 0])
+    assert np.argmin(k) == 1                       # equal cost -> lowest d
+    d, b = sharding.decode_keys(k)
+    assert list(d) == [9, 3, 0] and list(b) == [5.0, 5.0, 7.0]
+    d, b = sharding.decode_keys(sharding.encode_keys(c, np.arange(len(c))))
+    assert np.array_equal(b[2:], c[2:]) and b[1] == 0.0
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, cost_path, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cost = np.load(cost_path)                       # aggregated + padded DSI [H, W, D]
+    D = cost.shape[2]
+    d0, n = sharding.slab_bounds(D, world, rank)
+    slab = cost[:, :, d0:d0 + n]
+    local = np.argmin(slab, axis=2)                 # first minimum inside the slab
+    best = np.take_along_axis(slab, local[..., None], axis=2)[..., 0]
+    keys = torch.from_numpy(sharding.encode_keys(best, local + d0).T.copy())   # column-major
+    sharding.all_reduce_min_keys(keys)
+    if rank == 0:
+        np.save(out_path, keys.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gloo_slab_merge_equals_oracle_wta(oracle, tmp_path, world):
+    w, h, D = 72, 20, 24
+    left, right = synth.noise_pair(w, h, 1)
+    p = oracle.make_params(w, h, 1, disp_max=D - 1, match_fn=1, match_max=2, aggr_window_size=5)
+    cost = oracle.aggregate(oracle.raw_costs(left, right, p), p)     # many ties (match_max 2)
+    want_d, want_b = oracle.wta(cost)
+    cp, op = str(tmp_path / "cost.npy"), str(tmp_path / "keys.npy")
+    np.save(cp, cost)
+    mp.spawn(_worker, args=(world, _free_port(), cp, op), nprocs=world, join=True)
+    d, b = sharding.decode_keys(np.load(op).T)
+    assert np.array_equal(d, want_d)
+    util.assert_bit_equal(b, want_b, "merged best cost")
