@@ -1,0 +1,324 @@
+// StereoMatcher.cpp -- stage sequencing of the reference (StereoMatcher.cpp:38-181,
+// StcAggregate.cpp:255-365, StcOptimize.cpp:162-280, StcRefine.cpp:28-39) over the C-ABI.
+#include "StereoMatcher.h"
+#include "Error.h"
+#include <cmath>
+#include <ctime>
+
+#define ROUND(x) ((int)((x) >= 0 ? (x) + .5 : (x) - .5))
+
+CStereoMatcher::CStereoMatcher()
+{
+    for (int i = 0; i < B_COUNT; i++) { m_dev[i] = nullptr; m_dev_bytes[i] = 0; }
+    if (smhip_init(0, &m_ctx) != SMHIP_OK)      // device 0, like prepareDevice (CudaUtilities.cu:124)
+        throw CError("%s", smhip_last_error());
+}
+
+CStereoMatcher::~CStereoMatcher()
+{
+    if (!m_ctx)
+        return;
+    for (int i = 0; i < B_COUNT; i++)
+        if (m_dev[i]) smhip_free(m_ctx, m_dev[i]);
+    smhip_shutdown(m_ctx);
+}
+
+void CStereoMatcher::Check(int rc)
+{
+    if (rc != SMHIP_OK)
+        throw CError("%s", smhip_last_error());
+}
+
+void *CStereoMatcher::DeviceBuffer(int slot, size_t bytes)
+{
+    if (m_dev_bytes[slot] < bytes) {
+        if (m_dev[slot]) Check(smhip_free(m_ctx, m_dev[slot]));
+        m_dev[slot] = nullptr; m_dev_bytes[slot] = 0;
+        Check(smhip_malloc(m_ctx, bytes, &m_dev[slot]));
+        m_dev_bytes[slot] = bytes;
+    }
+    return m_dev[slot];
+}
+
+bool CStereoMatcher::Fusable() const
+{
+    // one box iteration + WTA and nothing downstream needs the full DSI
+    return allow_fused && aggr_fn == eBox && aggr_iter == 1 && aggr_minfilter <= 1 && opt_fn == eWTA &&
+           !refine_subpix && !aggr_subpixel && !aggr_collapse && !eval_match_quality &&
+           m_disp_den == 1 && verbose < eVerboseDumpFiles;
+}
+
+void CStereoMatcher::ComputeCorrespondence()
+{
+    if (frame_ref < 0 || frame_ref >= (int)m_frame.size())
+        throw CError("ComputeCorrespondence: invalid reference frame number %d", frame_ref);
+    if (frame_match < 0 || frame_match >= (int)m_frame.size())
+        throw CError("ComputeCorrespondence: invalid matching frame number %d", frame_match);
+    CByteImage &ref = m_frame[frame_ref].input_image;
+    CByteImage &mat = m_frame[frame_match].input_image;
+    CShape sh0 = ref.Shape(), sh1 = mat.Shape();
+    if (sh0.width * sh0.height == 0)
+        throw CError("ComputeCorrespondence: invalid reference image");
+    if (sh1.width * sh1.height == 0)
+        throw CError("ComputeCorrespondence: invalid matching image");
+    if (sh0 != sh1)
+        throw CError("ComputeCorrespondence: reference and matching not the same size");
+    m_frame_diff = frame_match - frame_ref;
+    m_frame_diff_sign = (m_frame_diff > 0) ? 1 : -1;
+
+    const float min_precision = 1e-3f;
+    if (disp_step <= 0.0 ||
+        (disp_step < 1.0 && fabs(1.0 / disp_step - ROUND(1.0 / disp_step)) > min_precision) ||
+        (disp_step > 1.0 && fabs(disp_step - ROUND(disp_step)) > min_precision))
+        throw CError("ComputeCorrespondence: disp_step must integer N or 1.0/N");
+    m_disp_num = disp_step < 1.0f ? 1 : ROUND(disp_step);
+    m_disp_den = disp_step < 1.0f ? ROUND(1.0 / disp_step) : 1;
+    disp_step = m_disp_num / (float)m_disp_den;
+    m_disp_step_inv = m_disp_den / (float)m_disp_num;
+    disp_n = int(m_disp_step_inv * (disp_max - disp_min)) + 1;
+    m_disp_step = disp_step;
+    m_disp_n = disp_n;
+    if (verbose >= eVerboseProgress)
+        fprintf(stderr, "\nComputing correspondence between frames %d and %d\n"
+                        "disp_n = %d, disp_min = %d, m_disp_num = %d, m_disp_den = %d, disp_scale = %g\n",
+                frame_ref, frame_match, disp_n, disp_min, m_disp_num, m_disp_den, disp_scale);
+    if (evaluate_only)
+        throw CError("ComputeCorrespondence: evaluate_only is not part of the device hot path");
+
+    m_reference = ref;
+    m_matching = mat;
+    CShape shD(sh0.width, sh0.height, 1);
+    CByteImage &depth_image = m_frame[frame_ref].depth_image;
+    if (depth_image.Shape() != shD)
+        depth_image.ReAllocate(shD);
+    m_float_disparity.ReAllocate(shD);
+    m_disparity.ReAllocate(shD);
+    m_best_cost.ReAllocate(shD);
+    if (m_disp_n < 2)
+        throw CError("ComputeCorrespondence: too few disparity levels (%d)", m_disp_n);
+
+    m_mp.width = sh0.width; m_mp.height = sh0.height; m_mp.n_bands = sh0.nBands;
+    m_mp.disp_min = disp_min; m_mp.disp_num = m_disp_num; m_mp.disp_den = m_disp_den;
+    m_mp.disp_n = m_disp_n; m_mp.frame_diff_sign = m_frame_diff_sign;
+    m_mp.match_fn = match_fn; m_mp.match_interp = match_interp; m_mp.match_max = match_max;
+    match_interval = match_interval ? 1 : 0;          // StcRawCosts.cpp:354
+    m_mp.match_interval = match_interval; m_mp.match_interpolated = match_interpolated;
+    m_match_outside = smhip_match_outside(&m_mp);
+
+    clock_t time0 = clock();
+    // images to the device (host rows are padded to 8 bytes; the pitch travels with them)
+    Check(smhip_memcpy_h2d(m_ctx, DeviceBuffer(B_REF, m_reference.ImageSize()), m_reference.Data(),
+                           m_reference.ImageSize()));
+    Check(smhip_memcpy_h2d(m_ctx, DeviceBuffer(B_MTC, m_matching.ImageSize()), m_matching.Data(),
+                           m_matching.ImageSize()));
+    size_t n_pix = (size_t)sh0.width * sh0.height;
+    DeviceBuffer(B_DISP, n_pix * sizeof(int32_t));
+    DeviceBuffer(B_BEST, n_pix * sizeof(float));
+
+    PreProcess();
+    m_used_fused = Fusable();
+    if (m_used_fused) {
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- fused device pass: costs, box filter (size %d), pad, WTA\n", aggr_window_size);
+        Check(smhip_fused_box_wta(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
+                                  m_reference.RowBytes(), &m_mp, aggr_window_size,
+                                  (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
+    } else {
+        RawCosts();
+        Aggregate();
+    }
+    Optimize();
+    Refine();
+    total_time = (float)(clock() - time0) / (float)CLOCKS_PER_SEC;
+    if (verbose >= eVerboseTiming)
+        fprintf(stderr, "* total time: %gs\n", total_time);
+
+    // depth map: uchar(clip(fdisp*disp_scale + (-disp_min*disp_scale + 0.5))), StereoMatcher.cpp:177
+    float offset = (float)(-disp_min * disp_scale + 0.5);
+    bool scale_offset = (disp_scale != 1.0f) || (offset != 0.0f);
+    for (int y = 0; y < shD.height; y++) {
+        const float *src = m_float_disparity.Row(y);
+        uchar *dst = depth_image.Row(y);
+        for (int x = 0; x < shD.width; x++) {
+            float val = scale_offset ? src[x] * disp_scale + offset : src[x];
+            val = val < 0.0f ? 0.0f : (val > 255.0f ? 255.0f : val);
+            dst[x] = (uchar)val;
+        }
+    }
+}
+
+void CStereoMatcher::PreProcess()
+{
+    if (preproc_blur_iter > 0 || preproc_addnoise_stddev > 0.0f)   // StcPreProcess.cpp:39-55
+        throw CError("PreProcess: input blur / noise is not part of the device hot path");
+}
+
+void CStereoMatcher::RawCosts()
+{
+    if (verbose >= eVerboseProgress)
+        fprintf(stderr, "- computing costs: %s%s%s\n", match_fn == eAD ? "AD" : "SD",
+                match_max < 1000 ? ", trunc" : "", match_interval ? ", interval" : "");
+    m_row_elems = (size_t)m_mp.width * m_disp_n;
+    DeviceBuffer(B_COST, m_row_elems * m_mp.height * sizeof(float));
+    Check(smhip_raw_costs(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
+                          m_reference.RowBytes(), &m_mp, (float *)m_dev[B_COST], m_row_elems));
+}
+
+void CStereoMatcher::AggrBox()
+{
+    Check(smhip_box_filter(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                           aggr_window_size, aggr_window_size, 1));
+}
+
+void CStereoMatcher::AggrMin()
+{
+    Check(smhip_min_filter(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                           aggr_minfilter, aggr_minfilter));
+}
+
+void CStereoMatcher::AggrDiffusion(int iter)
+{
+    size_t bytes = m_row_elems * m_mp.height * sizeof(float);
+    if (diff_beta > 0.0f && iter == 0)                       // StcDiffusion.cpp:52-56
+        Check(smhip_memcpy_d2d(m_ctx, DeviceBuffer(B_COST0, bytes), m_dev[B_COST], bytes));
+    DeviceBuffer(B_COST2, bytes);
+    Check(smhip_diffusion_iter(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                               diff_beta > 0.0f ? (const float *)m_dev[B_COST0] : nullptr, m_mp.width,
+                               m_mp.height, m_disp_n, m_row_elems, diff_lambda, diff_beta));
+    std::swap(m_dev[B_COST], m_dev[B_COST2]);                // StcDiffusion.cpp:58-63
+    std::swap(m_dev_bytes[B_COST], m_dev_bytes[B_COST2]);
+}
+
+void CStereoMatcher::PadCosts()
+{
+    Check(smhip_pad_costs(m_ctx, (float *)m_dev[B_COST], m_row_elems, &m_mp));
+}
+
+void CStereoMatcher::Aggregate()
+{
+    for (int iter = 0; iter < aggr_iter; iter++) {
+        switch (aggr_fn) {
+        case eBox:
+            if (verbose >= eVerboseProgress && iter < 3)
+                fprintf(stderr, "- aggregating: box filter, size %d\n", aggr_window_size);
+            AggrBox();
+            break;
+        case eBinomial:
+            if (verbose >= eVerboseProgress && iter < 3)
+                fprintf(stderr, "- aggregating: binomial 14641 filter\n");
+            Check(smhip_convolve_14641(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n,
+                                       m_row_elems));
+            break;
+        case eDiffusion:
+            if (verbose >= eVerboseProgress && iter < 3)
+                fprintf(stderr, "- aggregating: diffusion, lambda = %g\n", diff_lambda);
+            diff_beta = 0.0f;                                 // StcAggregate.cpp:305
+            AggrDiffusion(iter);
+            break;
+        case eMembrane:
+            if (verbose >= eVerboseProgress && iter < 3)
+                fprintf(stderr, "- aggregating: membrane model, lambda = %g, beta = %g\n", diff_lambda, diff_beta);
+            AggrDiffusion(iter);
+            break;
+        case eBayesian:
+            throw CError("CStereoMatcher::Aggregate(): Bayesian diffusion is not on the device path");
+        default:
+            throw CError("CStereoMatcher::Aggregate(): unknown aggregation function");
+        }
+    }
+    if (aggr_minfilter > 1) {
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- min filter (shiftable windows): filter size %d\n", aggr_minfilter);
+        AggrMin();
+    }
+    PadCosts();
+    if (aggr_subpixel || aggr_collapse)
+        throw CError("CStereoMatcher::Aggregate(): sub-pixel fit / collapse are not on the device path");
+}
+
+void CStereoMatcher::OptWTA()
+{
+    Check(smhip_wta(m_ctx, (const float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                    (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
+}
+
+void CStereoMatcher::Optimize()
+{
+    if (opt_fn != eWTA)
+        throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) is on the device path");
+    if (verbose >= eVerboseProgress)
+        fprintf(stderr, "- optimizing: WTA (local minimum)\n");
+    if (!m_used_fused)
+        OptWTA();
+    // results to the host (disparity rows are 4*W bytes: already a multiple of 8 or padded here)
+    size_t wbytes = (size_t)m_mp.width * 4;
+    Check(smhip_memcpy2d_d2h(m_ctx, m_disparity.Data(), m_disparity.RowBytes(), m_dev[B_DISP], wbytes, wbytes,
+                             m_mp.height));
+    Check(smhip_memcpy2d_d2h(m_ctx, m_best_cost.Data(), m_best_cost.RowBytes(), m_dev[B_BEST], wbytes, wbytes,
+                             m_mp.height));
+    if (final_energy < 0.0f) {                                // StcOptimize.cpp:270-278
+        float ed, en;
+        ComputeEnergy(ed, en);
+        final_energy = ed + en;
+    }
+}
+
+// Smoothness weight between two reference pixels (StcOptimize.cpp:61-82)
+static float NCost(const uchar *a, const uchar *b, int nB, float smoothness, float thresh, float penalty)
+{
+    float d2 = 0.0f;
+    for (int k = 0; k < nB; k++) {
+        float d = (float)(int(a[k]) - int(b[k]));
+        d2 += d * d;
+    }
+    d2 /= (nB - (nB > 1));
+    float s = smoothness;
+    if (sqrtf(d2) < thresh)
+        s *= penalty;
+    return s;
+}
+
+void CStereoMatcher::ComputeEnergy(float &denergy, float &nenergy)
+{
+    // data term: raster-order float sum of the cost at the winner; neighbour term: smoothness
+    // weight wherever adjacent labels differ (StcGraphCut.cpp:46-70, StcOptimize.cpp:103-116)
+    int W = m_mp.width, H = m_mp.height, nB = m_mp.n_bands;
+    float dSum = 0.0f, nSum = 0.0f;
+    for (int y = 0; y < H; y++) {
+        const int *cur = m_disparity.Row(y);
+        const int *nxt = m_disparity.Row(y + (y < H - 1));
+        const float *bc = m_best_cost.Row(y);
+        const uchar *i0 = m_reference.Row(y), *i1 = m_reference.Row(y + (y < H - 1));
+        for (int x = 0; x < W; x++) {
+            dSum += bc[x];
+            if (y < H - 1 && cur[x] != nxt[x])
+                nSum += NCost(i0 + x * nB, i1 + x * nB, nB, opt_smoothness, opt_grad_thresh, opt_grad_penalty);
+            if (x < W - 1 && cur[x] != cur[x + 1])
+                nSum += NCost(i0 + x * nB, i0 + (x + 1) * nB, nB, opt_smoothness, opt_grad_thresh,
+                              opt_grad_penalty);
+        }
+    }
+    denergy = dSum;
+    nenergy = nSum;
+}
+
+void CStereoMatcher::Refine()
+{
+    // m_float_disparity = disp * step + disp_min (StcRefine.cpp:34-39 via Convert.cpp:31-52)
+    float d_offset = (float)disp_min;
+    bool scale_offset = (m_disp_step != 1.0f) || (d_offset != 0.0f);
+    for (int y = 0; y < m_mp.height; y++) {
+        const int *src = m_disparity.Row(y);
+        float *dst = m_float_disparity.Row(y);
+        for (int x = 0; x < m_mp.width; x++)
+            dst[x] = scale_offset ? src[x] * m_disp_step + d_offset : (float)src[x];
+    }
+    if (refine_subpix)
+        throw CError("CStereoMatcher::Refine(): sub-pixel refinement is not on the device path");
+}
+
+void CStereoMatcher::Evaluate()
+{
+    // The evaluator (StcEvaluate.cpp) is outside the accelerated path; the error statistics keep
+    // their "not computed" value of -1 (ResetOutputParams).
+}

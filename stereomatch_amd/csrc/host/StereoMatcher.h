@@ -1,0 +1,56 @@
+// StereoMatcher.h -- CStereoMatcher: the pipeline driver of the hot path on the device.
+// Same entry points as the reference class (StereoMatcher.h:68-173): ComputeCorrespondence()
+// runs PreProcess -> RawCosts -> Aggregate -> Optimize -> Refine; the stage bodies call the
+// C-ABI of include/smhip.h instead of the CPU operators, and the disparity-space image stays
+// on the device between stages.
+#pragma once
+#include "../../../include/smhip.h"
+#include "Image.h"
+#include "StereoParameters.h"
+#include <vector>
+
+struct CStereoFrame {
+    CByteImage input_image, depth_image, truth_image, resampled_image;
+};
+
+class CStereoMatcher : public CStereoParameters {
+public:
+    CStereoMatcher();
+    ~CStereoMatcher();
+    void ComputeCorrespondence();
+    void Evaluate();                    // evaluator is outside the hot path: leaves the outputs at -1
+    bool UsedFusedPath() const { return m_used_fused; }
+    bool allow_fused = true;            // RawCosts+AggrBox+PadCosts+OptWTA in one device call when legal
+
+protected:
+    void PreProcess();
+    void RawCosts();
+    void Aggregate();
+    void Optimize();
+    void Refine();
+    void AggrBox();
+    void AggrDiffusion(int iter);
+    void AggrMin();
+    void PadCosts();
+    void OptWTA();
+    void ComputeEnergy(float &denergy, float &nenergy);
+
+    void Check(int rc);                 // smhip status -> CError
+    void *DeviceBuffer(int slot, size_t bytes);
+    bool Fusable() const;
+
+    smhip_ctx *m_ctx = nullptr;
+    smhip_match_params m_mp;
+    float m_disp_step, m_disp_step_inv, m_match_outside;
+    int m_disp_n, m_disp_num, m_disp_den, m_frame_diff, m_frame_diff_sign;
+    bool m_used_fused = false;
+    CByteImage m_reference, m_matching;
+    CIntImage m_disparity;              // winning levels [0 .. m_disp_n-1]
+    CFloatImage m_best_cost;            // m_cost at the winner (data term of final_energy)
+    CFloatImage m_float_disparity;
+    size_t m_row_elems = 0;
+    enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_COUNT };
+    void *m_dev[B_COUNT];
+    size_t m_dev_bytes[B_COUNT];
+    std::vector<CStereoFrame> m_frame;
+};
