@@ -100,12 +100,19 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
 /* MinFilter<float> (MinFilter.h:31, MinFilter.cpp:122-209), replicate border, in place */
 int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
                      size_t row_elems, int x_width, int y_width);
+/* the same, d_src -> d_dst (distinct buffers, as MinFilter(src, dst, ...) allows, MinFilter.h:31):
+ * one pass over the volume instead of filter + copy back; hosts swap m_cost / m_cost2 */
+int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w, int h,
+                        int n_bands, size_t row_elems, int x_width, int y_width);
 
 /* Replaces CudaConvolveXY(..., BINOMIAL14641) (CudaConvolve.h:57-58, Convolve.cpp:214-215)
  * with the semantics of the CPU ConvolveSeparable (Convolve.cpp:166-254): kernel 14641 in
  * x then y, replicate border, scale 1, offset 0, in place. */
 int smhip_convolve_14641(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
                          size_t row_elems);
+/* the same, d_src -> d_dst (distinct buffers, ConvolveSeparable(src, dst, ...), Convolve.h:55-60) */
+int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w, int h,
+                            int n_bands, size_t row_elems);
 
 /* One AggrDiffusion iteration (StcDiffusion.cpp:28-137) d_src -> d_dst (distinct buffers);
  * d_cost0 (the un-aggregated DSI) is read only when beta > 0 (membrane model). */

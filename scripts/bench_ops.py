@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Times the stage operators of the C-ABI on a resident DSI (BASELINE configs 2 and 4 shapes) and
+prints achieved GB/s against the algorithmic bytes of SURVEY 8d (8 bytes per voxel and filter
+application; WTA 4 bytes per voxel).  GPU box only:  python scripts/bench_ops.py [W H D]"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+from stereomatch_amd import capi, synth  # noqa: E402
+
+
+def main():
+    W, H, D = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (3840, 2160, 512)
+    reps = 5
+    ctx = capi.Context(0)
+    left, right, _ = synth.scene_pair(W, H, min(D, 256))
+    p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+    d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
+    N = W * H * D
+    re = W * D
+    cost, cost2 = ctx.alloc(N * 4), ctx.alloc(N * 4)
+    disp, best = ctx.alloc(W * H * 4), ctx.alloc(W * H * 4)
+    out = {}
+
+    def timed(name, nbytes, fn):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        out[name] = {"ms": round(ms, 3), "GB/s": round(nbytes / ms / 1e6, 1),
+                     "frac_of_8TBs": round(nbytes / ms / 1e6 / 8000, 3),
+                     "Gvox/s": round(N / ms / 1e6, 1)}
+        print("%-22s %9.3f ms  %8.1f GB/s  frac %.3f" % (name, ms, nbytes / ms / 1e6,
+                                                          nbytes / ms / 1e6 / 8000), flush=True)
+
+    timed("raw_costs (BT-SAD)", 4.0 * N, lambda: ctx.raw_costs(d_ref, d_mtc, W, p, cost, re))
+    timed("box_filter 9x9", 8.0 * N, lambda: ctx.box_filter(cost, W, H, D, re, 9))
+    timed("min_filter 9x9", 8.0 * N, lambda: ctx.min_filter(cost, W, H, D, re, 9))
+    timed("min_filter_to 9x9", 8.0 * N, lambda: ctx.min_filter_to(cost, cost2, W, H, D, re, 9))
+    timed("convolve_14641", 8.0 * N, lambda: ctx.convolve_14641(cost, W, H, D, re))
+    timed("convolve_14641_to", 8.0 * N, lambda: ctx.convolve_14641_to(cost, cost2, W, H, D, re))
+    timed("diffusion_iter", 8.0 * N, lambda: ctx.diffusion_iter(cost, cost2, None, W, H, D, re, 0.15, 0.0))
+    timed("membrane_iter", 12.0 * N, lambda: ctx.diffusion_iter(cost, cost2, cost, W, H, D, re, 0.15, 0.5))
+    timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
+    timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
+    print(json.dumps({"shape": [W, H, D], "ops": out}))
+
+
+if __name__ == "__main__":
+    main()

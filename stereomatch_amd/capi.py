@@ -17,7 +17,8 @@ SYMBOLS = [
     "smhip_init", "smhip_shutdown", "smhip_last_error", "smhip_set_stream", "smhip_sync",
     "smhip_workspace_bytes", "smhip_malloc", "smhip_free", "smhip_memcpy_h2d",
     "smhip_memcpy_d2h", "smhip_memcpy_d2d", "smhip_memcpy2d_h2d", "smhip_memcpy2d_d2h", "smhip_match_outside",
-    "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_convolve_14641",
+    "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_min_filter_to",
+    "smhip_convolve_14641", "smhip_convolve_14641_to",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
 ]
@@ -88,6 +89,8 @@ def load():
     L.smhip_box_filter.argtypes = [vp, vp, ci, ci, ci, sz, ci, ci, ci]
     L.smhip_min_filter.argtypes = [vp, vp, ci, ci, ci, sz, ci, ci]
     L.smhip_convolve_14641.argtypes = [vp, vp, ci, ci, ci, sz]
+    L.smhip_min_filter_to.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, ci]
+    L.smhip_convolve_14641_to.argtypes = [vp, vp, vp, ci, ci, ci, sz]
     L.smhip_diffusion_iter.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf]
     L.smhip_pad_costs.argtypes = [vp, vp, sz, pp]
     L.smhip_wta.argtypes = [vp, vp, ci, ci, ci, sz, vp, vp]
@@ -214,6 +217,14 @@ class Context:
 
     def convolve_14641(self, d_cost, w, h, nb, row_elems):
         self._chk(self.L.smhip_convolve_14641(self.h, _ptr(d_cost), w, h, nb, row_elems))
+
+    def min_filter_to(self, d_src, d_dst, w, h, nb, row_elems, x_width, y_width=None):
+        y_width = x_width if y_width is None else y_width
+        self._chk(self.L.smhip_min_filter_to(self.h, _ptr(d_src), _ptr(d_dst), w, h, nb, row_elems,
+                                             x_width, y_width))
+
+    def convolve_14641_to(self, d_src, d_dst, w, h, nb, row_elems):
+        self._chk(self.L.smhip_convolve_14641_to(self.h, _ptr(d_src), _ptr(d_dst), w, h, nb, row_elems))
 
     def diffusion_iter(self, d_src, d_dst, d_cost0, w, h, nb, row_elems, lam, beta):
         self._chk(self.L.smhip_diffusion_iter(self.h, _ptr(d_src), _ptr(d_dst), _ptr(d_cost0),

@@ -170,10 +170,18 @@ void CStereoMatcher::AggrBox()
                            aggr_window_size, aggr_window_size, 1));
 }
 
+void CStereoMatcher::SwapCost()
+{
+    std::swap(m_dev[B_COST], m_dev[B_COST2]);                // m_cost <-> m_cost2 (StcDiffusion.cpp:58-63)
+    std::swap(m_dev_bytes[B_COST], m_dev_bytes[B_COST2]);
+}
+
 void CStereoMatcher::AggrMin()
 {
-    Check(smhip_min_filter(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
-                           aggr_minfilter, aggr_minfilter));
+    DeviceBuffer(B_COST2, m_row_elems * m_mp.height * sizeof(float));
+    Check(smhip_min_filter_to(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2], m_mp.width,
+                              m_mp.height, m_disp_n, m_row_elems, aggr_minfilter, aggr_minfilter));
+    SwapCost();
 }
 
 void CStereoMatcher::AggrDiffusion(int iter)
@@ -185,8 +193,7 @@ void CStereoMatcher::AggrDiffusion(int iter)
     Check(smhip_diffusion_iter(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2],
                                diff_beta > 0.0f ? (const float *)m_dev[B_COST0] : nullptr, m_mp.width,
                                m_mp.height, m_disp_n, m_row_elems, diff_lambda, diff_beta));
-    std::swap(m_dev[B_COST], m_dev[B_COST2]);                // StcDiffusion.cpp:58-63
-    std::swap(m_dev_bytes[B_COST], m_dev_bytes[B_COST2]);
+    SwapCost();
 }
 
 void CStereoMatcher::PadCosts()
@@ -206,8 +213,10 @@ void CStereoMatcher::Aggregate()
         case eBinomial:
             if (verbose >= eVerboseProgress && iter < 3)
                 fprintf(stderr, "- aggregating: binomial 14641 filter\n");
-            Check(smhip_convolve_14641(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n,
-                                       m_row_elems));
+            DeviceBuffer(B_COST2, m_row_elems * m_mp.height * sizeof(float));
+            Check(smhip_convolve_14641_to(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                                          m_mp.width, m_mp.height, m_disp_n, m_row_elems));
+            SwapCost();
             break;
         case eDiffusion:
             if (verbose >= eVerboseProgress && iter < 3)

@@ -37,6 +37,7 @@ protected:
 
     void Check(int rc);                 // smhip status -> CError
     void *DeviceBuffer(int slot, size_t bytes);
+    void SwapCost();
     bool Fusable() const;
 
     smhip_ctx *m_ctx = nullptr;

@@ -3,6 +3,7 @@
 #include "smhip_kernels.h"
 #include "smhip_fused.h"
 #include "smhip_fused_b.h"
+#include "smhip_stencil.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -334,6 +335,66 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     return SMHIP_OK;
 }
 
+// floats per thread of the column-walk kernels: 4 when every row, the level count and the
+// base pointers keep 16-byte alignment, else 1
+static int walk_vec(int nb, size_t row_elems, const void *p0, const void *p1, const void *p2)
+{
+    uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
+    return (nb % 4 == 0 && row_elems % 4 == 0 && (bits & 15) == 0) ? 4 : 1;
+}
+
+static dim3 walk_grid(int w, int nb, int h, int vec, int seglen)
+{
+    long threads = ((long)w * nb + vec - 1) / vec;
+    return dim3((unsigned)((threads + 255) / 256), (unsigned)((h + seglen - 1) / seglen));
+}
+
+int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w, int h, int nb,
+                        size_t row_elems, int x_width, int y_width)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_src, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_dst || d_dst == d_src)
+        return fail(SMHIP_EINVAL, "MinFilter: source and destination must differ");
+    if (x_width < 1 || y_width < 1)
+        return fail(SMHIP_EINVAL, "MinFilter: bad window %dx%d", x_width, y_width);
+    const int seglen = 128;
+    int vec = walk_vec(nb, row_elems, d_src, d_dst, nullptr);
+    dim3 grid = walk_grid(w, nb, h, vec, seglen);
+#define LAUNCH_MIN(WIN)                                                                              \
+    do {                                                                                             \
+        if (vec == 4)                                                                                \
+            smk::minfilter_walk_kernel<4, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
+                                                                            row_elems, seglen);     \
+        else                                                                                         \
+            smk::minfilter_walk_kernel<1, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
+                                                                            row_elems, seglen);     \
+    } while (0)
+    if (x_width == y_width && x_width == 9) {
+        LAUNCH_MIN(9);
+    } else if (x_width == y_width && x_width == 5) {
+        LAUNCH_MIN(5);
+    } else if (x_width == y_width && x_width == 3) {
+        LAUNCH_MIN(3);
+    } else {
+        // general window: horizontal pass into the workspace, vertical pass into the destination
+        void *tmp = nullptr;
+        rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+        if (rc) return rc;
+        if (tmp == d_src || tmp == d_dst)
+            return fail(SMHIP_EINVAL, "MinFilter: buffers alias the context workspace");
+        dim3 g2((w * nb + 255) / 256, h);
+        smk::min_h_kernel<<<g2, 256, 0, ctx->stream>>>(d_src, (float *)tmp, w, nb, row_elems, x_width);
+        smk::min_v_kernel<<<g2, 256, 0, ctx->stream>>>((const float *)tmp, d_dst, w * nb, h, row_elems,
+                                                      y_width);
+    }
+#undef LAUNCH_MIN
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
 int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t row_elems,
                      int x_width, int y_width)
 {
@@ -344,12 +405,42 @@ int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     if (x_width < 1 || y_width < 1)
         return fail(SMHIP_EINVAL, "MinFilter: bad window %dx%d", x_width, y_width);
     void *tmp = nullptr;
-    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    size_t bytes = row_elems * (size_t)h * sizeof(float);
+    if (x_width == y_width && (x_width == 9 || x_width == 5 || x_width == 3)) {
+        rc = ws_get(ctx, WS_TMP, bytes, &tmp);
+        if (rc) return rc;
+        rc = smhip_min_filter_to(ctx, d_cost, (float *)tmp, w, h, nb, row_elems, x_width, y_width);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpy2DAsync(d_cost, row_elems * sizeof(float), tmp, row_elems * sizeof(float),
+                                     (size_t)w * nb * sizeof(float), h, hipMemcpyDeviceToDevice, ctx->stream));
+        return SMHIP_OK;
+    }
+    rc = ws_get(ctx, WS_TMP, bytes, &tmp);
     if (rc) return rc;
     dim3 grid((w * nb + 255) / 256, h);
     smk::min_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems, x_width);
     smk::min_v_kernel<<<grid, 256, 0, ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems,
                                                     y_width);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w, int h, int nb,
+                            size_t row_elems)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_src, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_dst || d_dst == d_src)
+        return fail(SMHIP_EINVAL, "ConvolveSeparable: source and destination must differ");
+    const int seglen = 64;
+    int vec = walk_vec(nb, row_elems, d_src, d_dst, nullptr);
+    dim3 grid = walk_grid(w, nb, h, vec, seglen);
+    if (vec == 4)
+        smk::binomial_walk_kernel<4><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
+    else
+        smk::binomial_walk_kernel<1><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -361,12 +452,13 @@ int smhip_convolve_14641(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, si
     rc = check_dsi(d_cost, w, h, nb, row_elems);
     if (rc) return rc;
     void *tmp = nullptr;
-    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    size_t bytes = row_elems * (size_t)h * sizeof(float);
+    rc = ws_get(ctx, WS_TMP, bytes, &tmp);
     if (rc) return rc;
-    dim3 grid((w * nb + 255) / 256, h);
-    smk::binom_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems);
-    smk::binom_v_kernel<<<grid, 256, 0, ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems);
-    HIP_TRY(hipGetLastError());
+    rc = smhip_convolve_14641_to(ctx, d_cost, (float *)tmp, w, h, nb, row_elems);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy2DAsync(d_cost, row_elems * sizeof(float), tmp, row_elems * sizeof(float),
+                                 (size_t)w * nb * sizeof(float), h, hipMemcpyDeviceToDevice, ctx->stream));
     return SMHIP_OK;
 }
 
@@ -383,9 +475,15 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst, const
         return fail(SMHIP_EINVAL, "membrane model (beta > 0) needs the initial DSI");
     float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
     float lb = lambda * beta;            // :132
-    dim3 grid((w * nb + 255) / 256, h);
-    smk::diffusion_kernel<<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, d_cost0, w, nb, h, row_elems,
-                                                        lambda, a, lb, beta > 0.0f);
+    const int seglen = 64;
+    const bool mem = beta > 0.0f;
+    int vec = walk_vec(nb, row_elems, d_src, d_dst, mem ? d_cost0 : nullptr);
+    dim3 grid = walk_grid(w, nb, h, vec, seglen);
+#define LAUNCH_DIFF(V, M) smk::diffusion_walk_kernel<V, M><<<grid, 256, 0, ctx->stream>>>( \
+        d_src, d_dst, d_cost0, w * nb, nb, h, row_elems, seglen, lambda, a, lb)
+    if (vec == 4) { if (mem) LAUNCH_DIFF(4, true); else LAUNCH_DIFF(4, false); }
+    else          { if (mem) LAUNCH_DIFF(1, true); else LAUNCH_DIFF(1, false); }
+#undef LAUNCH_DIFF
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

@@ -1,0 +1,174 @@
+// smhip_stencil.h -- "column walk" kernels for the per-plane stencils on a resident DSI:
+// diffusion / membrane (StcDiffusion.cpp:28-137), separable binomial 14641
+// (Convolve.cpp:86-254) and the separable min filter (MinFilter.cpp:122-202).
+//
+// Common shape: a thread owns V consecutive floats (V = 4: one dwordx4) of a row -- i.e. V
+// levels of one pixel, levels on lanes -- and walks a segment of rows serially, keeping the
+// vertical neighbourhood in registers.  Every element is therefore read once from HBM as a
+// "centre"; the horizontal neighbours (x +- 1, x +- 2, ... at the same level, D floats
+// away) are the centres of nearby waves and come from L1/L2.  One kernel per application,
+// source and destination distinct: HBM traffic = read once + write once = 8 bytes per voxel.
+// All arithmetic is per element and keeps the reference's operation order.
+#pragma once
+
+#include "smhip_kernels.h"
+
+namespace smk {
+
+template <int V> struct fvec { typedef float type __attribute__((ext_vector_type(V))); };
+template <> struct fvec<1> { typedef float type; };
+
+template <int V>
+__device__ __forceinline__ typename fvec<V>::type vload(const float *p)
+{
+    return *(const typename fvec<V>::type *)p;
+}
+template <int V>
+__device__ __forceinline__ void vstore(float *p, typename fvec<V>::type v)
+{
+    *(typename fvec<V>::type *)p = v;
+}
+
+// ---- diffusion / membrane --------------------------------------------------------------
+// o = a*c + lambda*(((l + r) + u) + d), a missing neighbour replaced by c in its slot
+// (StcDiffusion.cpp:84-99, :112-118); membrane adds (lambda*beta)*cost0 afterwards (:122-136).
+template <int V, bool MEMBRANE>
+__global__ __launch_bounds__(256) void diffusion_walk_kernel(
+    const float *__restrict__ src, float *__restrict__ dst, const float *__restrict__ cost0,
+    int WD, int D, int H, size_t row_elems, int seglen, float lambda, float a, float lb)
+{
+    typedef typename fvec<V>::type vec;
+    const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (j >= WD)
+        return;
+    const int y0 = blockIdx.y * seglen, y1 = min(H, y0 + seglen);
+    const long lf = (j - D >= 0) ? -(long)D : 0;
+    const long rt = (j + D < WD) ? (long)D : 0;
+    const float *s = src + (size_t)y0 * row_elems + j;
+    float *o = dst + (size_t)y0 * row_elems + j;
+    const float *c0 = MEMBRANE ? cost0 + (size_t)y0 * row_elems + j : nullptr;
+    vec cur = vload<V>(s);
+    vec up = (y0 > 0) ? vload<V>(s - row_elems) : cur;
+    for (int y = y0; y < y1; y++) {
+        vec dn = (y < H - 1) ? vload<V>(s + row_elems) : cur;
+        vec l = vload<V>(s + lf), r = vload<V>(s + rt);
+        vec v = a * cur + lambda * (((l + r) + up) + dn);
+        if (MEMBRANE) {
+            v += lb * vload<V>(c0);
+            c0 += row_elems;
+        }
+        vstore<V>(o, v);
+        up = cur;
+        cur = dn;
+        s += row_elems;
+        o += row_elems;
+    }
+}
+
+// ---- separable binomial 14641 ------------------------------------------------------------
+// horizontal: t = ((((0 + k0*s[x-2]) + k1*s[x-1]) + k2*s[x]) + k3*s[x+1]) + k4*s[x+2], replicate
+// border; vertical: the same over t, top row first (Convolve.cpp:96-110, :224-225).
+template <int V>
+__device__ __forceinline__ typename fvec<V>::type vtap5(typename fvec<V>::type s0, typename fvec<V>::type s1,
+                                                        typename fvec<V>::type s2, typename fvec<V>::type s3,
+                                                        typename fvec<V>::type s4)
+{
+    typename fvec<V>::type acc = 0.0f;
+    acc += 0.0625f * s0;
+    acc += 0.25f * s1;
+    acc += 0.375f * s2;
+    acc += 0.25f * s3;
+    acc += 0.0625f * s4;
+    return acc;
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void binomial_walk_kernel(const float *__restrict__ src,
+                                                            float *__restrict__ dst, int W, int D, int H,
+                                                            size_t row_elems, int seglen)
+{
+    typedef typename fvec<V>::type vec;
+    const long WD = (long)W * D;
+    const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (j >= WD)
+        return;
+    const int x = (int)(j / D);
+    const long o0 = (long)(clampi(x - 2, W) - x) * D, o1 = (long)(clampi(x - 1, W) - x) * D;
+    const long o3 = (long)(clampi(x + 1, W) - x) * D, o4 = (long)(clampi(x + 2, W) - x) * D;
+    auto hrow = [&](int yy) -> vec {
+        const float *r = src + (size_t)clampi(yy, H) * row_elems + j;
+        return vtap5<V>(vload<V>(r + o0), vload<V>(r + o1), vload<V>(r), vload<V>(r + o3), vload<V>(r + o4));
+    };
+    const int y0 = blockIdx.y * seglen, y1 = min(H, y0 + seglen);
+    vec h0 = hrow(y0 - 2), h1 = hrow(y0 - 1), h2 = hrow(y0), h3 = hrow(y0 + 1);
+    float *o = dst + (size_t)y0 * row_elems + j;
+    for (int y = y0; y < y1; y++) {
+        vec h4 = hrow(y + 2);
+        vstore<V>(o, vtap5<V>(h0, h1, h2, h3, h4));
+        h0 = h1; h1 = h2; h2 = h3; h3 = h4;
+        o += row_elems;
+    }
+}
+
+// ---- separable min filter -----------------------------------------------------------------
+// o[y][x] = min over rows y+pl+1..y+pr of (min over x+pl+1..x+pr), replicate border
+// (MinFilter.cpp:139-140, :49-52); min is exact in any order.  WIN is the (square) window.
+template <int V>
+__device__ __forceinline__ typename fvec<V>::type vmin(typename fvec<V>::type a, typename fvec<V>::type b)
+{
+    if constexpr (V == 1) {
+        return b < a ? b : a;
+    } else {
+        typename fvec<V>::type r;
+#pragma unroll
+        for (int i = 0; i < V; i++)
+            r[i] = b[i] < a[i] ? b[i] : a[i];
+        return r;
+    }
+}
+
+template <int V, int WIN>
+__global__ __launch_bounds__(256) void minfilter_walk_kernel(const float *__restrict__ src,
+                                                             float *__restrict__ dst, int W, int D, int H,
+                                                             size_t row_elems, int seglen)
+{
+    typedef typename fvec<V>::type vec;
+    constexpr int PR = WIN / 2, PL = PR - WIN;
+    const long WD = (long)W * D;
+    const long j = ((long)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    if (j >= WD)
+        return;
+    const int x = (int)(j / D);
+    long off[WIN];
+#pragma unroll
+    for (int k = 0; k < WIN; k++)
+        off[k] = (long)(clampi(x + PL + 1 + k, W) - x) * D;
+    auto hrow = [&](int yy) -> vec {
+        const float *r = src + (size_t)clampi(yy, H) * row_elems + j;
+        vec m = vload<V>(r + off[0]);
+#pragma unroll
+        for (int k = 1; k < WIN; k++)
+            m = vmin<V>(m, vload<V>(r + off[k]));
+        return m;
+    };
+    const int y0 = blockIdx.y * seglen, y1 = min(H, y0 + seglen);
+    vec ring[WIN];                      // ring[k] = horizontal min of row y + PL + 1 + k
+#pragma unroll
+    for (int k = 0; k < WIN - 1; k++)
+        ring[k + 1] = hrow(y0 + PL + 1 + k);
+    float *o = dst + (size_t)y0 * row_elems + j;
+    for (int y = y0; y < y1; y++) {
+#pragma unroll
+        for (int k = 0; k < WIN - 1; k++)
+            ring[k] = ring[k + 1];
+        ring[WIN - 1] = hrow(y + PR);
+        vec m = ring[0];
+#pragma unroll
+        for (int k = 1; k < WIN; k++)
+            m = vmin<V>(m, ring[k]);
+        vstore<V>(o, m);
+        o += row_elems;
+    }
+}
+
+}  // namespace smk

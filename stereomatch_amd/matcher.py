@@ -149,7 +149,10 @@ class StereoMatcher(StereoParameters):
             if self.aggr_fn == eBox:
                 c.box_filter(self.d_cost, w, h, nb, re, self.aggr_window_size)
             elif self.aggr_fn == eBinomial:
-                c.convolve_14641(self.d_cost, w, h, nb, re)
+                other = self._buf("cost2", nbytes)      # ConvolveSeparable(src, dst, ...): ping-pong
+                c.convolve_14641_to(self.d_cost, other, w, h, nb, re)
+                self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+                self.d_cost = other
             elif self.aggr_fn in (eDiffusion, eMembrane):
                 other = self._buf("cost2", nbytes)                      # StcDiffusion.cpp:58-63
                 c.diffusion_iter(self.d_cost, other, cost0, w, h, nb, re, self.diff_lambda, beta)
@@ -158,7 +161,10 @@ class StereoMatcher(StereoParameters):
             else:
                 raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
         if self.aggr_minfilter > 1:                                      # :351-360
-            c.min_filter(self.d_cost, w, h, nb, re, self.aggr_minfilter)
+            other = self._buf("cost2", nbytes)
+            c.min_filter_to(self.d_cost, other, w, h, nb, re, self.aggr_minfilter)
+            self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+            self.d_cost = other
         c.pad_costs(self.d_cost, re, p)                                  # :365
 
     def Optimize(self):  # StcOptimize.cpp:162-280, WTA only

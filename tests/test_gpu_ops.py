@@ -177,3 +177,27 @@ def test_error_reporting(gpu_ctx):
     p = capi.match_params(64, 64, 1, 8, disp_den=2)
     with pytest.raises(capi.SmhipError):
         gpu_ctx.raw_costs(buf, buf, 64, p, buf, 512)
+
+
+@pytest.mark.parametrize("h,w,d,pad", SHAPES + [(140, 30, 8, 0), (70, 21, 12, 4)])
+def test_out_of_place_filters(gpu_ctx, oracle, h, w, d, pad):
+    """smhip_min_filter_to / smhip_convolve_14641_to: one pass src -> dst (column-walk kernels);
+    tall shapes cross the row-segment boundaries of those kernels."""
+    c = util.rand_dsi(h, w, d, 60, "float")
+    re = w * d + pad
+    host = np.zeros((h, re), np.float32)
+    host[:, :w * d] = c.reshape(h, w * d)
+    src, dst = up(gpu_ctx, host), gpu_ctx.alloc(h * re * 4)
+    def get():
+        return gpu_ctx.download(dst, (h, re), np.float32)[:, :w * d].reshape(h, w, d)
+    for win in (9, 5, 3, 4, 7):
+        if win - win // 2 >= min(w, h):
+            continue
+        gpu_ctx.min_filter_to(src, dst, w, h, d, re, win)
+        util.assert_bit_equal(get(), oracle.min_filter(c, win), "min_to %d" % win)
+    gpu_ctx.convolve_14641_to(src, dst, w, h, d, re)
+    util.assert_bit_equal(get(), oracle.convolve_14641(c), "binomial_to")
+    # the source is untouched
+    util.assert_bit_equal(gpu_ctx.download(src, (h, re), np.float32), host, "source")
+    with pytest.raises(capi.SmhipError):
+        gpu_ctx.convolve_14641_to(src, src, w, h, d, re)
