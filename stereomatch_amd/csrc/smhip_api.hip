@@ -586,7 +586,8 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     int n_chunks = Dp / CH;
     size_t n_pix = (size_t)W * H;
     const bool wide = (Dp % 64 == 0);
-    const bool tuned_a = wide && p->n_bands == 1;
+    const bool tuned_a = wide && (p->n_bands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
+                                                      ((uintptr_t)d_mtc & 3) == 0));
     // banded slab layout (smhip_fused.h) only when both passes are the tuned kernels
     int tyshift = tuned_a ? 5 : 0;
     if (const char *e = getenv("SMHIP_TYSHIFT")) { if (tuned_a) tyshift = atoi(e); }
@@ -623,14 +624,30 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         fa.disp0 = a.disp0; fa.dstep = a.dstep; fa.cutoff = a.cutoff; fa.outside = a.outside;
         int tpa = Dp < 256 ? Dp : 256;
         dim3 ga(H, Dp / tpa);
-        size_t lds = (size_t)W * 2 * sizeof(uint16_t);
+        const int nbands = p->n_bands;
+        size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
-#define LAUNCH_A(WIN, SD) smk::fused_rawbox_h_lds_kernel<WIN, SD><<<ga, tpa, lds, ctx->stream>>>( \
+#define LAUNCH_A3(WIN, SD, NB) smk::fused_rawbox_h_lds_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>( \
         fa, (float *)T, tyshift, Dp, window, scale)
-        if (window == 9) { if (a.sd) LAUNCH_A(9, true); else LAUNCH_A(9, false); }
-        else             { if (a.sd) LAUNCH_A(0, true); else LAUNCH_A(0, false); }
+#define LAUNCH_A(WIN)                                                             \
+        do {                                                                      \
+            if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
+            else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \
+        } while (0)
+        switch (window) {            // static windows: the leaving cost comes from a register ring
+        case 3: LAUNCH_A(3); break;
+        case 5: LAUNCH_A(5); break;
+        case 7: LAUNCH_A(7); break;
+        case 9: LAUNCH_A(9); break;
+        case 11: LAUNCH_A(11); break;
+        case 13: LAUNCH_A(13); break;
+        case 15: LAUNCH_A(15); break;
+        case 17: LAUNCH_A(17); break;
+        default: LAUNCH_A(0); break;
+        }
 #undef LAUNCH_A
+#undef LAUNCH_A3
     } else {
         long chains = (long)H * Dp;
         smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
@@ -652,7 +669,14 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         case 2: LAUNCH_BT(WIN, 2); break;              \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
-        if (window == 9) { LAUNCH_BW(9) } else { LAUNCH_BW(0) }
+        switch (window) {            // static windows: the leaving row comes from registers
+        case 3: LAUNCH_BW(3) break;
+        case 5: LAUNCH_BW(5) break;
+        case 7: LAUNCH_BW(7) break;
+        case 9: LAUNCH_BW(9) break;
+        case 11: LAUNCH_BW(11) break;
+        default: LAUNCH_BW(0) break;
+        }
 #undef LAUNCH_BW
 #undef LAUNCH_BT
     } else {

@@ -3,10 +3,10 @@
 //
 // Pass A  (fused_rawbox_h_lds_kernel): one workgroup = one image row x up to 256 levels.
 //   The row of the reference image and the (min,max) Birchfield-Tomasi row of the matching
-//   image are staged once in LDS (2 x 2 bytes per pixel); each lane then walks x serially,
-//   evaluating ONE new integer raw cost per step and taking the cost that leaves the window
-//   from a register ring (window size is a template parameter, so ring slots are static).
-//   Each step a wave stores 64 consecutive floats (256 B) of the slab T.
+//   image are staged once in LDS (4 bytes per pixel and band); each lane then walks x
+//   serially, evaluating ONE new integer raw cost per step and taking the cost that leaves
+//   the window from a register ring (window size is a template parameter, so ring slots are
+//   static).  Each step a wave stores 64 consecutive floats (256 B) of the slab T.
 //   HBM traffic: W*H*Dp*4 bytes written, images read once.
 #pragma once
 
@@ -18,7 +18,7 @@ namespace smk {
 // rows; element (y, x, k) lives at
 //     (((y >> tyshift) * W + x) << tyshift) * Dp + (y & (TY-1)) * Dp + k.
 // tyshift = 0 is the plain [y][x][k] layout.  Bands make the H concurrent row streams of
-// pass A land in H/TY compact windows (measured: 8..10 % faster slab writes, reads unchanged).
+// pass A land in H/TY compact windows (measured: 4..10 % faster slab writes, reads unchanged).
 __device__ __forceinline__ size_t slab_row_offset(int y, int W, int Dp, int tyshift)
 {
     return (((size_t)(y >> tyshift) * W) << tyshift) * Dp + (size_t)(y & ((1 << tyshift) - 1)) * Dp;
@@ -33,40 +33,67 @@ struct FusedA {
     int cutoff, outside;
 };
 
-// One raw cost (n_bands = 1).  Rl: packed (rn | rx << 8) per pixel, Ml: packed (mn | mx << 8).
-template <bool SD>
-__device__ __forceinline__ int cost1(const uint16_t *Rl, const uint16_t *Ml, int x, int disp, int W,
-                                     int cutoff, int outside)
-{
-    int xm = x + disp;
-    bool out = (unsigned)xm >= (unsigned)W;
-    int xc = (int)min((unsigned)xm, (unsigned)(W - 1));
-    int r = Rl[x], m = Ml[xc];
-    int rn = r & 0xFF, rx = r >> 8, mn = m & 0xFF, mx = m >> 8;
-    // gap between [rn,rx] and [mn,mx] (StcRawCosts.cpp:168-180); with point intervals this is |m - r|
-    int e = max(max(mn - rx, rn - mx), 0);
-    if (SD)
-        e = e * e;
-    e = min(e, cutoff);
-    return out ? outside : e;
-}
+// Staged image rows.  NB = 1: one uint16 per pixel, (lower | upper << 8).  NB = 4: one uint32
+// of the four lower ends and one of the four upper ends per pixel.
+template <int NB> struct RowLds;
+template <> struct RowLds<1> {
+    uint16_t *r, *m;
+    __device__ static size_t bytes(int W) { return (size_t)W * 4; }
+    __device__ void init(void *base, int W) { r = (uint16_t *)base; m = r + W; }
+    __device__ void stage(const FusedA &a, size_t ro, int i) const
+    {
+        r[i] = (uint16_t)(a.rn[ro + i] | (a.rx[ro + i] << 8));
+        m[i] = (uint16_t)(a.mn[ro + i] | (a.mx[ro + i] << 8));
+    }
+    // distance between the intervals of reference pixel xr and matching pixel xm
+    // (StcRawCosts.cpp:168-180; with point intervals it is |m - r|), summed over bands
+    template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
+    {
+        int a = r[xr], b = m[xm];
+        int e = max(max((b & 0xFF) - (a >> 8), (a & 0xFF) - (b >> 8)), 0);
+        return SD ? e * e : e;
+    }
+};
+template <> struct RowLds<4> {
+    uint32_t *rn, *rx, *mn, *mx;
+    __device__ static size_t bytes(int W) { return (size_t)W * 16; }
+    __device__ void init(void *base, int W) { rn = (uint32_t *)base; rx = rn + W; mn = rx + W; mx = mn + W; }
+    __device__ void stage(const FusedA &a, size_t ro, int i) const
+    {
+        rn[i] = *(const uint32_t *)(a.rn + ro + 4 * (size_t)i);
+        rx[i] = *(const uint32_t *)(a.rx + ro + 4 * (size_t)i);
+        mn[i] = *(const uint32_t *)(a.mn + ro + 4 * (size_t)i);
+        mx[i] = *(const uint32_t *)(a.mx + ro + 4 * (size_t)i);
+    }
+    template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
+    {
+        uint32_t an = rn[xr], ax = rx[xr], bn = mn[xm], bx = mx[xm];
+        int sum = 0;
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            int e = max(max((int)((bn >> s) & 0xFF) - (int)((ax >> s) & 0xFF),
+                            (int)((an >> s) & 0xFF) - (int)((bx >> s) & 0xFF)), 0);
+            sum += SD ? e * e : e;
+        }
+        return sum;
+    }
+};
 
-template <int WIN, bool SD>
+template <int WIN, bool SD, int NB>
 __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float *__restrict__ T,
                                                                  int tyshift, int Dp, int win,
                                                                  float scale)
 {
-    extern __shared__ uint16_t lds_a[];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_a[];
     const int W = a.W;
-    uint16_t *Rl = lds_a, *Ml = lds_a + W;
+    RowLds<NB> L;
+    L.init(lds_a, W);
     const int y = blockIdx.x;
     const int k = blockIdx.y * blockDim.x + threadIdx.x;
     {
         const size_t ro = (size_t)y * a.pitch;
-        for (int i = threadIdx.x; i < W; i += blockDim.x) {
-            Rl[i] = (uint16_t)(a.rn[ro + i] | (a.rx[ro + i] << 8));
-            Ml[i] = (uint16_t)(a.mn[ro + i] | (a.mx[ro + i] << 8));
-        }
+        for (int i = threadIdx.x; i < W; i += blockDim.x)
+            L.stage(a, ro, i);
     }
     __syncthreads();
     if (k >= a.D)
@@ -78,12 +105,21 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
     const int w = WIN ? WIN : win;
     const int pr = w / 2, pl = pr - w;
 
+    // MatchLine (StcRawCosts.cpp:152-198) for reference pixel x at this lane's level
+    auto cost = [&](int x) -> int {
+        int xm = x + disp;
+        bool out = (unsigned)xm >= (unsigned)W;
+        int xc = (int)min((unsigned)xm, (unsigned)(W - 1));
+        int e = min(L.template gap<SD>(x, xc), cutoff);
+        return out ? outside : e;
+    };
+
     float acc = 0;
     if (WIN) {
         int ring[WIN ? WIN : 1];
 #pragma unroll
         for (int j = 0; j < WIN; j++) {
-            int c = cost1<SD>(Rl, Ml, clampi(pl + 1 + j, W), disp, W, cutoff, outside);
+            int c = cost(clampi(pl + 1 + j, W));
             ring[j] = c;
             acc += scale * (float)c;
         }
@@ -100,11 +136,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
 #pragma unroll
                 for (int s = 0; s < WIN; s++) {
                     int x = xb + s;
-                    int r = Rl[x + pr], m = Ml[x + pr + disp];
-                    int e = max(max((m & 0xFF) - (r >> 8), (r & 0xFF) - (m >> 8)), 0);
-                    if (SD)
-                        e = e * e;
-                    int c = min(e, cutoff);
+                    int c = min(L.template gap<SD>(x + pr, x + pr + disp), cutoff);
                     acc = acc + scale * (float)(c - ring[s]);
                     ring[s] = c;
                     t[xs * x] = acc;
@@ -113,7 +145,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
 #pragma unroll
                 for (int s = 0; s < WIN; s++) {
                     int x = xb + s;
-                    int c = cost1<SD>(Rl, Ml, min(x + pr, W - 1), disp, W, cutoff, outside);
+                    int c = cost(min(x + pr, W - 1));
                     acc = acc + scale * (float)(c - ring[s]);
                     ring[s] = c;
                     if ((unsigned)(x + disp) < (unsigned)W)   // PadCosts overwrites the rest: never read
@@ -125,7 +157,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
         for (int s = 0; s < WIN; s++) {
             int x = xb + s;
             if (x < W) {
-                int c = cost1<SD>(Rl, Ml, min(x + pr, W - 1), disp, W, cutoff, outside);
+                int c = cost(min(x + pr, W - 1));
                 acc = acc + scale * (float)(c - ring[s]);
                 ring[s] = c;
                 if ((unsigned)(x + disp) < (unsigned)W)
@@ -134,11 +166,11 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
         }
     } else {
         for (int i = pl + 1; i <= pr; i++)
-            acc += scale * (float)cost1<SD>(Rl, Ml, clampi(i, W), disp, W, cutoff, outside);
+            acc += scale * (float)cost(clampi(i, W));
         t[0] = acc;
         for (int x = 1; x < W; x++) {
-            int cl = cost1<SD>(Rl, Ml, max(x + pl, 0), disp, W, cutoff, outside);
-            int cr = cost1<SD>(Rl, Ml, min(x + pr, W - 1), disp, W, cutoff, outside);
+            int cl = cost(max(x + pl, 0));
+            int cr = cost(min(x + pr, W - 1));
             acc = acc + scale * (float)(cr - cl);
             if ((unsigned)(x + disp) < (unsigned)W)
                 t[xs * x] = acc;
