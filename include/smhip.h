@@ -86,7 +86,9 @@ float smhip_match_outside(const smhip_match_params *p);
 
 /* Replaces LineProcess (CudaRawCosts.h:145, called from RawCostsGPU StcRawCosts.cpp:305);
  * arithmetic of RawCostsCPU/MatchLine/BirchfieldTomasiMinMax/InterpolateLine
- * (StcRawCosts.cpp:67-218, 327-435). */
+ * (StcRawCosts.cpp:67-218, 327-435).  disp_den > 1 (disp_step = 1/den) up-samples both
+ * lines den times (linear or cubic) and, with match_interpolated, averages 2*(den/2)+1
+ * sample costs per pixel, as the reference does. */
 int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                     size_t img_pitch, const smhip_match_params *p,
                     float *d_cost, size_t row_elems);
@@ -120,7 +122,7 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst,
                          const float *d_cost0, int w, int h, int n_bands,
                          size_t row_elems, float lambda, float beta);
 
-/* PadCosts (StcRawCosts.cpp:437-476) */
+/* PadCosts (StcRawCosts.cpp:437-476), any disp_den */
 int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems,
                     const smhip_match_params *p);
 
@@ -138,7 +140,8 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
  * ordered_bits() maps float order to int32 order, so min(key) over slabs (e.g. an
  * int64 MIN all-reduce across GPUs) is OptWTA's winner with its lowest-d tie break.
  * d_keys holds width*height keys, COLUMN-MAJOR: the key of pixel (x, y) is d_keys[x*height + y]
- * (each wave owns a pixel column and stores runs of consecutive rows). */
+ * (each wave owns a pixel column and stores runs of consecutive rows).
+ * Integer-pel steps only (disp_den == 1); fractional steps go through the stage calls. */
 int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                              size_t img_pitch, const smhip_match_params *p, int window,
                              int d_first, int d_count, int64_t *d_keys);

@@ -4,6 +4,7 @@
 #include "smhip_fused.h"
 #include "smhip_fused_b.h"
 #include "smhip_stencil.h"
+#include "smhip_subpix.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -100,9 +101,8 @@ int check_params(const smhip_match_params *p, const void *d_ref, const void *d_m
         return fail(SMHIP_EINVAL, "unknown match_fn %d", p->match_fn);
     if (p->disp_num < 1 || p->disp_den < 1)
         return fail(SMHIP_EINVAL, "bad disparity step %d/%d", p->disp_num, p->disp_den);
-    if (p->disp_den != 1)
-        return fail(SMHIP_EINVAL, "disp_step < 1 (sub-pixel DSI, den=%d) is not implemented on the device",
-                    p->disp_den);
+    if (((size_t)p->disp_den * (p->width - 1) + 1) * p->n_bands > 0x7FFFFFFFul)
+        return fail(SMHIP_EINVAL, "up-sampled line (den=%d) exceeds 2^31 samples", p->disp_den);
     if (p->frame_diff_sign != 1 && p->frame_diff_sign != -1)
         return fail(SMHIP_EINVAL, "frame_diff_sign must be +1 or -1");
     return SMHIP_OK;
@@ -152,6 +152,47 @@ int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size
         }
         HIP_TRY(hipGetLastError());
     }
+    return SMHIP_OK;
+}
+
+// disp_step = 1/den: up-samples both images into int16 line buffers (and their
+// Birchfield-Tomasi intervals) in the WS_BT slot and fills SubpixArgs for all levels.
+int prepare_subpix(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t pitch,
+                   const smhip_match_params *p, smk::SubpixArgs *s)
+{
+    int W = p->width, H = p->height, nb = p->n_bands, den = p->disp_den;
+    int n = den * (W - 1) + 1;
+    size_t len = (size_t)n * nb * H;             // samples per buffer
+    void *ws = nullptr;
+    int rc = ws_get(ctx, WS_BT, len * 6 * sizeof(int16_t), &ws);
+    if (rc) return rc;
+    int16_t *buf0 = (int16_t *)ws, *buf1 = buf0 + len;
+    int16_t *min1 = buf1 + len, *max1 = min1 + len, *min0 = max1 + len, *max0 = min0 + len;
+    int cubic = p->match_interp == 3;            // eCubic, StereoParameters.h:44
+    dim3 gi((W * nb + 255) / 256, H), gs((n * nb + 255) / 256, H);
+    smk::interp_lines_kernel<<<gi, 256, 0, ctx->stream>>>(d_ref, pitch, buf0, W, H, nb, den, cubic);
+    smk::interp_lines_kernel<<<gi, 256, 0, ctx->stream>>>(d_mtc, pitch, buf1, W, H, nb, den, cubic);
+    s->rmn = buf0; s->rmx = nullptr;
+    s->mmn = buf1; s->mmx = nullptr;
+    if (p->match_interval) {
+        smk::bt_minmax16_kernel<<<gs, 256, 0, ctx->stream>>>(buf1, min1, max1, n, H, nb);
+        s->mmn = min1; s->mmx = max1;
+        if (p->match_interpolated) {
+            smk::bt_minmax16_kernel<<<gs, 256, 0, ctx->stream>>>(buf0, min0, max0, n, H, nb);
+            s->rmn = min0; s->rmx = max0;
+        } else {
+            s->rmx = buf0;
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    s->W = W; s->H = H; s->nb = nb; s->n = n; s->den = den;
+    s->D = p->disp_n;
+    s->dstep = -p->frame_diff_sign * p->disp_num;
+    s->disp0 = -p->frame_diff_sign * (den * p->disp_min);
+    s->sd = p->match_fn == 2;
+    s->cutoff = cutoff_of(p);
+    s->interpolated = p->match_interpolated != 0;
+    s->outside = (float)outside_of(p);
     return SMHIP_OK;
 }
 
@@ -298,10 +339,20 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
     if (rc) return rc;
     rc = check_dsi(d_cost, p->width, p->height, p->disp_n, row_elems);
     if (rc) return rc;
+    if ((size_t)p->width * p->disp_n > 0x7FFFFFFFul)
+        return fail(SMHIP_EINVAL, "width*levels exceeds 2^31");
+    dim3 grid((p->width * p->disp_n + 255) / 256, p->height);
+    if (p->disp_den > 1) {
+        smk::SubpixArgs s;
+        rc = prepare_subpix(ctx, d_ref, d_mtc, img_pitch, p, &s);
+        if (rc) return rc;
+        smk::raw_costs_subpix_kernel<<<grid, 256, 0, ctx->stream>>>(s, d_cost, row_elems);
+        HIP_TRY(hipGetLastError());
+        return SMHIP_OK;
+    }
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, 0, p->disp_n, &a);
     if (rc) return rc;
-    dim3 grid((p->width * p->disp_n + 255) / 256, p->height);
     smk::raw_costs_kernel<<<grid, 256, 0, ctx->stream>>>(a, d_cost, row_elems);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -496,8 +547,19 @@ int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip
         return fail(SMHIP_EINVAL, "null parameters");
     rc = check_dsi(d_cost, p->width, p->height, p->disp_n, row_elems);
     if (rc) return rc;
-    if (p->disp_den != 1)
-        return fail(SMHIP_EINVAL, "disp_step < 1 is not implemented on the device");
+    if (p->disp_num < 1 || p->disp_den < 1)
+        return fail(SMHIP_EINVAL, "bad disparity step %d/%d", p->disp_num, p->disp_den);
+    if (p->disp_den > 1) {
+        if ((size_t)p->width * p->disp_n > 0x7FFFFFFFul)
+            return fail(SMHIP_EINVAL, "width*levels exceeds 2^31");
+        int den = p->disp_den, n = den * (p->width - 1) + 1;
+        dim3 grid((p->width * p->disp_n + 255) / 256, p->height);
+        smk::pad_costs_subpix_kernel<<<grid, 256, 0, ctx->stream>>>(
+            d_cost, row_elems, p->width, p->disp_n, n, den, -p->frame_diff_sign * (den * p->disp_min),
+            -p->frame_diff_sign * p->disp_num, smhip_match_outside(p));
+        HIP_TRY(hipGetLastError());
+        return SMHIP_OK;
+    }
     int dstep = -p->frame_diff_sign * p->disp_num;
     int disp0 = -p->frame_diff_sign * p->disp_min;
     int dlast = disp0 + (p->disp_n - 1) * dstep;
@@ -557,6 +619,9 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     if (rc) return rc;
     rc = check_params(p, d_ref, d_mtc, img_pitch);
     if (rc) return rc;
+    if (p->disp_den != 1)   // the hosts route disp_step < 1 through the staged entry points
+        return fail(SMHIP_EINVAL, "fused path: disp_step < 1 (den=%d) not supported, use smhip_raw_costs",
+                    p->disp_den);
     if (!d_keys)
         return fail(SMHIP_EINVAL, "null key buffer");
     if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
@@ -742,7 +807,7 @@ int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_
     if (ms_pass_a) *ms_pass_a = a;
     if (ms_pass_b) *ms_pass_b = b;
     for (int i = 0; i < 3 * ctx->ev_cap; i++)
-        hipEventDestroy(ctx->ev[i]);
+        (void)hipEventDestroy(ctx->ev[i]);
     free(ctx->ev);
     ctx->ev = nullptr;
     ctx->ev_cap = ctx->ev_used = 0;

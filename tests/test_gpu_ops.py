@@ -60,6 +60,46 @@ def test_raw_costs(gpu_ctx, oracle, w, h, b, D, dmin, sign, fn, mmax, interval, 
                           oracle.pad_costs(want, po), "pad costs")
 
 
+SUBPIX_CASES = [
+    # w, h, b, dmin, dmax, den, sign, fn, mmax, interp(1 linear / 3 cubic), interval, interpolated
+    (37, 7, 1, 0, 4, 2, 1, 1, 1000, 3, 0, 0),
+    (37, 7, 1, 0, 4, 2, 1, 2, 1000, 1, 0, 0),
+    (40, 6, 4, 0, 3, 4, 1, 1, 20, 3, 1, 0),
+    (40, 6, 4, 1, 4, 3, -1, 2, 30, 1, 1, 1),
+    (33, 5, 1, 0, 5, 4, 1, 1, 1000, 3, 1, 1),
+    (33, 5, 1, 0, 5, 2, -1, 1, 1000, 3, 0, 1),
+    (29, 4, 4, 0, 2, 5, 1, 2, 1000, 3, 0, 1),
+    (64, 3, 1, 2, 9, 8, 1, 1, 7, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("w,h,b,dmin,dmax,den,sign,fn,mmax,minterp,interval,interp", SUBPIX_CASES)
+def test_raw_costs_subpixel(gpu_ctx, oracle, w, h, b, dmin, dmax, den, sign, fn, mmax, minterp,
+                            interval, interp):
+    """disp_step = 1/den: InterpolateLine (linear / cubic), BT on the up-sampled lines and the
+    interpolated-cost average (StcRawCosts.cpp:67-218), then PadCosts with den > 1.  The
+    reference holds no golden output for disp_step < 1: parity is against the oracle only
+    (parity unpinned)."""
+    ref, mtc = synth.noise_pair(w, h, b, seed=synth.SEED_NOISE + den)
+    fr, fm = (0, 1) if sign > 0 else (1, 0)
+    po = oracle.make_params(w, h, b, disp_min=dmin, disp_max=dmax, disp_step=1.0 / den,
+                            frame_ref=fr, frame_match=fm, match_fn=fn, match_max=mmax,
+                            match_interp=minterp, match_interval=interval,
+                            match_interpolated=interp)
+    D = po.disp_n
+    assert po.disp_den == den and D == den * (dmax - dmin) + 1
+    want = oracle.raw_costs(ref, mtc, po)
+    p = capi.match_params(w, h, b, D, disp_min=dmin, disp_den=den, frame_diff_sign=sign,
+                          match_fn=fn, match_interp=minterp, match_max=mmax,
+                          match_interval=interval, match_interpolated=interp)
+    cost = gpu_ctx.alloc(w * h * D * 4)
+    gpu_ctx.raw_costs(up(gpu_ctx, ref), up(gpu_ctx, mtc), w * b, p, cost, w * D)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32), want, "sub-pixel raw costs")
+    gpu_ctx.pad_costs(cost, w * D, p)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32),
+                          oracle.pad_costs(want, po), "sub-pixel pad costs")
+
+
 def test_raw_costs_pitched_images(gpu_ctx, oracle):
     """Images whose rows are padded to 8 bytes (Image.cpp:97-98): W*b = 37 -> pitch 40."""
     w, h, b, D = 37, 6, 1, 8
@@ -175,8 +215,9 @@ def test_error_reporting(gpu_ctx):
         gpu_ctx.raw_costs(buf, buf, 64, p, buf, 64)
     assert "too few disparity levels" in str(e.value)             # StereoMatcher.cpp:158-159
     p = capi.match_params(64, 64, 1, 8, disp_den=2)
-    with pytest.raises(capi.SmhipError):
-        gpu_ctx.raw_costs(buf, buf, 64, p, buf, 512)
+    with pytest.raises(capi.SmhipError) as e:                     # fused path: integer steps only
+        gpu_ctx.fused_box_wta(buf, buf, 64, p, 5, buf, buf)
+    assert "disp_step < 1" in str(e.value)
 
 
 @pytest.mark.parametrize("h,w,d,pad", SHAPES + [(140, 30, 8, 0), (70, 21, 12, 4)])

@@ -58,3 +58,26 @@ def test_full_dsi_vs_oracle(gpu_ctx, tsukuba, oracle, name):
     want = oracle.aggregate(oracle.raw_costs(ref, mtc, p), p)
     m, _, _, _ = run(gpu_ctx, tsukuba, kw, fused=False)
     util.assert_bit_equal(m.download_cost(), want, name)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(disp_step=0.5, match_fn=1, match_interval=1, match_interpolated=1, aggr_window_size=9),
+    dict(disp_step=0.25, match_fn=2, match_interp=1, match_max=20, aggr_window_size=5,
+         aggr_minfilter=5),
+    dict(disp_step=0.5, match_fn=1, match_interval=1, aggr_fn=3, aggr_iter=4),
+])
+def test_subpixel_step_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
+    """disp_step = 1/2, 1/4 end to end (staged path: raw costs on up-sampled lines, aggregation,
+    PadCosts, WTA, depth scaling with the fractional step).  No reference output exists for
+    these settings: checked against the oracle only (parity unpinned)."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    seq = dict(util.TSUKUBA_SEQ)
+    p = oracle.make_params(w, h, b, **seq, **kw)
+    odisp, obest, odepth, _ = oracle.compute_correspondence(ref, mtc, p)
+    m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+    disp, best, depth = m.ComputeCorrespondence(ref, mtc)
+    assert not m.used_fused and m.m_disp_n == p.disp_n
+    util.assert_bit_equal(disp, odisp, "disparity")
+    util.assert_bit_equal(best, obest, "best cost")
+    assert np.array_equal(depth, odepth.reshape(depth.shape))
