@@ -5,6 +5,7 @@
 #include "smhip_fused_b.h"
 #include "smhip_stencil.h"
 #include "smhip_subpix.h"
+#include "smhip_stage.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -153,6 +154,14 @@ int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size
         HIP_TRY(hipGetLastError());
     }
     return SMHIP_OK;
+}
+
+// floats per thread of the column-walk kernels: 4 when every row, the level count and the
+// base pointers keep 16-byte alignment, else 1
+static int walk_vec(int nb, size_t row_elems, const void *p0, const void *p1, const void *p2)
+{
+    uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
+    return (nb % 4 == 0 && row_elems % 4 == 0 && (bits & 15) == 0) ? 4 : 1;
 }
 
 // disp_step = 1/den: up-samples both images into int16 line buffers (and their
@@ -353,7 +362,30 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, 0, p->disp_n, &a);
     if (rc) return rc;
-    smk::raw_costs_kernel<<<grid, 256, 0, ctx->stream>>>(a, d_cost, row_elems);
+    const int nbands = p->n_bands, W = p->width, H = p->height;
+    const bool img_ok = nbands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
+                                        ((uintptr_t)d_mtc & 3) == 0);
+    const size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
+    if (img_ok && lds <= 150 * 1024 && walk_vec(p->disp_n, row_elems, d_cost, nullptr, nullptr) == 4) {
+        smk::FusedA fa;
+        fa.rn = a.rmn; fa.rx = a.rmx ? a.rmx : a.rmn;
+        fa.mn = a.mmn; fa.mx = a.mmx ? a.mmx : a.mmn;
+        fa.pitch = img_pitch; fa.W = W; fa.H = H; fa.D = p->disp_n;
+        fa.disp0 = a.disp0; fa.dstep = a.dstep; fa.cutoff = a.cutoff; fa.outside = a.outside;
+        int nseg = (4096 + H - 1) / H;                 // >= 4096 workgroups when the row allows it
+        int xseg = (W + nseg - 1) / nseg;
+        if (xseg < 32) xseg = W < 32 ? W : 32;
+        dim3 gr((W + xseg - 1) / xseg, H);
+        if (nbands == 1) {
+            if (a.sd) smk::raw_costs_rows_kernel<true, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            else      smk::raw_costs_rows_kernel<false, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+        } else {
+            if (a.sd) smk::raw_costs_rows_kernel<true, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            else      smk::raw_costs_rows_kernel<false, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+        }
+    } else {
+        smk::raw_costs_kernel<<<grid, 256, 0, ctx->stream>>>(a, d_cost, row_elems);
+    }
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -376,22 +408,33 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
     if (rc) return rc;
     float scale = (float)(average ? 1.0 / win : 1);   // BoxFilter.cpp:89
-    long nh = (long)h * nb;
-    smk::box_lines_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
-        d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, win, scale);
-    long nv = (long)w * nb;
-    smk::box_lines_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
-        (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, win, scale);
+    long nh = (long)h * nb, nv = (long)w * nb;
+    const int vec = walk_vec(nb, row_elems, d_cost, tmp, nullptr);
+    const long th = nh / vec, tv = nv / vec;
+#define LAUNCH_BOX2(V, WIN)                                                                        \
+    do {                                                                                           \
+        smk::box_h_walk_kernel<V, WIN><<<(unsigned)((th + 255) / 256), 256, 0, ctx->stream>>>(     \
+            d_cost, (float *)tmp, w, h, nb, row_elems, scale);                                     \
+        smk::box_v_walk_kernel<V, WIN><<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>(     \
+            (const float *)tmp, d_cost, nv, h, row_elems, scale);                                  \
+    } while (0)
+#define LAUNCH_BOX(WIN) do { if (vec == 4) LAUNCH_BOX2(4, WIN); else LAUNCH_BOX2(1, WIN); } while (0)
+    switch (win) {               // static windows: register ring, every element loaded once
+    case 3: LAUNCH_BOX(3); break;
+    case 5: LAUNCH_BOX(5); break;
+    case 7: LAUNCH_BOX(7); break;
+    case 9: LAUNCH_BOX(9); break;
+    case 11: LAUNCH_BOX(11); break;
+    default:
+        smk::box_lines_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
+            d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, win, scale);
+        smk::box_lines_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
+            (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, win, scale);
+    }
+#undef LAUNCH_BOX
+#undef LAUNCH_BOX2
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
-}
-
-// floats per thread of the column-walk kernels: 4 when every row, the level count and the
-// base pointers keep 16-byte alignment, else 1
-static int walk_vec(int nb, size_t row_elems, const void *p0, const void *p1, const void *p2)
-{
-    uintptr_t bits = (uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2;
-    return (nb % 4 == 0 && row_elems % 4 == 0 && (bits & 15) == 0) ? 4 : 1;
 }
 
 static dim3 walk_grid(int w, int nb, int h, int vec, int seglen)
@@ -584,7 +627,21 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
     if (!d_disp && !d_best)
         return fail(SMHIP_EINVAL, "no output requested");
     long n_pix = (long)w * h;
-    if (nb >= 64) {
+    if (nb <= 1024 && walk_vec(nb, row_elems, d_cost, nullptr, nullptr) == 4) {
+        if (nb >= 128) {
+            const int run = 16;                        // pixels per wave
+            long waves = (n_pix + run - 1) / run;
+            unsigned blocks = (unsigned)((waves + 3) / 4);
+            int nv = (nb + 255) / 256;
+            if (nv == 1)      smk::wta_vec_kernel<1><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else if (nv == 2) smk::wta_vec_kernel<2><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else if (nv == 3) smk::wta_vec_kernel<3><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else              smk::wta_vec_kernel<4><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+        } else {
+            smk::wta_thread_vec_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+                d_cost, w, h, nb, row_elems, d_disp, d_best);
+        }
+    } else if (nb >= 64) {
         long blocks = (n_pix + 3) / 4;
         if (blocks > 256 * 32) blocks = 256 * 32;
         smk::wta_wave_kernel<<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems,

@@ -36,6 +36,9 @@ RAW_CASES = [
     (41, 8, 4, 12, 1, -1, 2, 50, 0, 0),
     (45, 6, 4, 8, 0, 1, 1, 1000, 1, 1),
     (130, 5, 1, 100, 0, 1, 1, 2, 1, 0),
+    (300, 4, 1, 260, 0, 1, 1, 1000, 1, 0),
+    (90, 3, 4, 1028, 3, -1, 2, 1000, 1, 1),
+    (70, 5, 1, 20, -7, 1, 1, 9, 0, 0),
 ]
 
 
@@ -118,11 +121,11 @@ def test_raw_costs_pitched_images(gpu_ctx, oracle):
 
 
 SHAPES = [(13, 17, 5, 0), (20, 33, 16, 0), (9, 21, 3, 1), (24, 40, 64, 0), (12, 19, 100, 0),
-          (10, 15, 7, 1)]
+          (10, 15, 7, 1), (31, 29, 8, 4), (27, 30, 12, 2)]
 
 
 @pytest.mark.parametrize("h,w,d,pad", SHAPES)
-@pytest.mark.parametrize("win", [3, 4, 9])
+@pytest.mark.parametrize("win", [3, 4, 5, 9, 11, 13])
 def test_box_filter(gpu_ctx, oracle, h, w, d, pad, win):
     c = util.rand_dsi(h, w, d, 10 + win)
     got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.box_filter(b, W, H, D, re, win), pad)
@@ -184,7 +187,9 @@ def test_diffusion(gpu_ctx, oracle, h, w, d, pad, beta):
     util.assert_bit_equal(got, oracle.diffusion_iter(c, 0.15, beta, c0), "diffusion")
 
 
-@pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (3, 5, 300)])
+@pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (3, 5, 300),
+                                   (3, 37, 128), (5, 19, 512), (3, 9, 1024), (3, 9, 640), (3, 5, 1100),
+                                   (4, 7, 132)])
 def test_wta(gpu_ctx, oracle, h, w, d):
     c = util.rand_dsi(h, w, d, 50)
     c[0, 0, :] = 5.0
