@@ -466,7 +466,20 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
             smk::minfilter_walk_kernel<1, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
                                                                             row_elems, seglen);     \
     } while (0)
-    if (x_width == y_width && x_width == 9) {
+    const int tseg = h >= 1024 ? 128 : 64;
+    dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
+#define LAUNCH_TMIN(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32><<<tgrid, 256, 0, ctx->stream>>>( \
+        d_src, d_dst, w, nb, h, row_elems, tseg)
+    if (vec == 4 && x_width == y_width && x_width % 2 == 1 && x_width >= 3 && x_width <= 11 &&
+        tgrid.y <= 65535 && tgrid.z <= 65535) {
+        switch (x_width) {
+        case 3: LAUNCH_TMIN(3); break;
+        case 5: LAUNCH_TMIN(5); break;
+        case 7: LAUNCH_TMIN(7); break;
+        case 9: LAUNCH_TMIN(9); break;
+        default: LAUNCH_TMIN(11); break;
+        }
+    } else if (x_width == y_width && x_width == 9) {
         LAUNCH_MIN(9);
     } else if (x_width == y_width && x_width == 5) {
         LAUNCH_MIN(5);
@@ -485,6 +498,7 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
                                                       y_width);
     }
 #undef LAUNCH_MIN
+#undef LAUNCH_TMIN
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -500,7 +514,9 @@ int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
         return fail(SMHIP_EINVAL, "MinFilter: bad window %dx%d", x_width, y_width);
     void *tmp = nullptr;
     size_t bytes = row_elems * (size_t)h * sizeof(float);
-    if (x_width == y_width && (x_width == 9 || x_width == 5 || x_width == 3)) {
+    const bool tiled = walk_vec(nb, row_elems, d_cost, nullptr, nullptr) == 4 && x_width % 2 == 1 &&
+                       x_width >= 3 && x_width <= 11;
+    if (x_width == y_width && (tiled || x_width == 9 || x_width == 5 || x_width == 3)) {
         rc = ws_get(ctx, WS_TMP, bytes, &tmp);
         if (rc) return rc;
         rc = smhip_min_filter_to(ctx, d_cost, (float *)tmp, w, h, nb, row_elems, x_width, y_width);
@@ -531,7 +547,12 @@ int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, in
     const int seglen = 64;
     int vec = walk_vec(nb, row_elems, d_src, d_dst, nullptr);
     dim3 grid = walk_grid(w, nb, h, vec, seglen);
-    if (vec == 4)
+    const int tseg = h >= 1024 ? 128 : 64;
+    dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
+    if (vec == 4 && tgrid.y <= 65535 && tgrid.z <= 65535)
+        smk::tile_walk_kernel<smk::BinomOp, 32><<<tgrid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h,
+                                                                               row_elems, tseg);
+    else if (vec == 4)
         smk::binomial_walk_kernel<4><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
     else
         smk::binomial_walk_kernel<1><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);

@@ -171,4 +171,96 @@ __global__ __launch_bounds__(256) void minfilter_walk_kernel(const float *__rest
     }
 }
 
+// ---- LDS-tiled separable stencils ----------------------------------------------------------
+// Workgroup = TX pixels x 32 levels (8 lanes of dwordx4 per pixel), walking a segment of rows.
+// Each row of the tile plus its horizontal halo goes through LDS once (double buffered, one
+// barrier per row): a thread takes its WIN horizontal neighbours from LDS instead of WIN global
+// loads, and keeps the WIN horizontally-filtered rows of the vertical window in registers.
+// HBM traffic: (1 + (WIN-1)/TX) reads + 1 write per voxel.
+template <int WIN_> struct MinOp {
+    static constexpr int WIN = WIN_;
+    typedef typename fvec<4>::type vec;
+    static __device__ __forceinline__ vec h(const vec *w)
+    {
+        vec m = w[0];
+#pragma unroll
+        for (int k = 1; k < WIN; k++)
+            m = vmin<4>(m, w[k]);
+        return m;
+    }
+    static __device__ __forceinline__ vec v(const vec *r) { return h(r); }
+};
+struct BinomOp {
+    static constexpr int WIN = 5;
+    typedef typename fvec<4>::type vec;
+    static __device__ __forceinline__ vec h(const vec *w) { return vtap5<4>(w[0], w[1], w[2], w[3], w[4]); }
+    static __device__ __forceinline__ vec v(const vec *r) { return vtap5<4>(r[0], r[1], r[2], r[3], r[4]); }
+};
+
+template <class OP, int TX>
+__global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restrict__ src,
+                                                           float *__restrict__ dst, int W, int D, int H,
+                                                           size_t row_elems, int seglen)
+{
+    typedef typename fvec<4>::type vec;
+    constexpr int WIN = OP::WIN, PR = WIN / 2, PL = PR - WIN;
+    constexpr int HX = TX + WIN - 1;               // pixels per staged row
+    constexpr int NT = TX * 8, NL = (HX * 8 + NT - 1) / NT;
+    __shared__ vec lds[2][HX * 8];
+    const int t = threadIdx.x, px = t >> 3, lq = t & 7;
+    const int x0 = blockIdx.x * TX, k0 = blockIdx.y * 32;
+    const int y0 = blockIdx.z * seglen, y1 = min(H, y0 + seglen);
+    size_t goff[NL];
+    bool gact[NL];
+#pragma unroll
+    for (int n = 0; n < NL; n++) {
+        int i = t + n * NT, hp = i >> 3, hl = i & 7;
+        gact[n] = (i < HX * 8) && (k0 + hl * 4 < D);
+        goff[n] = (size_t)clampi(x0 + PL + 1 + hp, W) * D + k0 + hl * 4;
+    }
+    vec g[NL];
+#pragma unroll
+    for (int n = 0; n < NL; n++)
+        g[n] = 0.0f;
+    auto gload = [&](int yy) {
+        const float *r = src + (size_t)clampi(yy, H) * row_elems;
+#pragma unroll
+        for (int n = 0; n < NL; n++)
+            if (gact[n])
+                g[n] = vload<4>(r + goff[n]);
+    };
+    const bool live = (x0 + px < W) && (k0 + lq * 4 < D);
+    float *o = dst + (size_t)y0 * row_elems + (size_t)min(x0 + px, W - 1) * D + min(k0 + lq * 4, D - 4);
+    vec ring[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; j++)
+        ring[j] = 0.0f;
+    int buf = 0;
+    const int ylast = y1 - 1 + PR;
+    gload(y0 + PL + 1);
+    for (int yy = y0 + PL + 1; yy <= ylast; yy++) {
+#pragma unroll
+        for (int n = 0; n < NL; n++)
+            if (t + n * NT < HX * 8)
+                lds[buf][t + n * NT] = g[n];
+        if (yy < ylast)
+            gload(yy + 1);
+        __syncthreads();
+        vec w[WIN];
+#pragma unroll
+        for (int j = 0; j < WIN; j++)
+            w[j] = lds[buf][(px + j) * 8 + lq];
+#pragma unroll
+        for (int j = 0; j < WIN - 1; j++)
+            ring[j] = ring[j + 1];
+        ring[WIN - 1] = OP::h(w);
+        if (yy - PR >= y0) {
+            if (live)
+                vstore<4>(o, OP::v(ring));
+            o += row_elems;
+        }
+        buf ^= 1;
+    }
+}
+
 }  // namespace smk

@@ -149,7 +149,7 @@ def test_box_filter_sum_mode(gpu_ctx, oracle):
 
 
 @pytest.mark.parametrize("h,w,d,pad", SHAPES)
-@pytest.mark.parametrize("win", [2, 3, 9])
+@pytest.mark.parametrize("win", [2, 3, 7, 9])
 def test_min_filter(gpu_ctx, oracle, h, w, d, pad, win):
     c = util.rand_dsi(h, w, d, 20 + win, "float")
     got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.min_filter(b, W, H, D, re, win), pad)
@@ -236,7 +236,7 @@ def test_out_of_place_filters(gpu_ctx, oracle, h, w, d, pad):
     src, dst = up(gpu_ctx, host), gpu_ctx.alloc(h * re * 4)
     def get():
         return gpu_ctx.download(dst, (h, re), np.float32)[:, :w * d].reshape(h, w, d)
-    for win in (9, 5, 3, 4, 7):
+    for win in (9, 5, 3, 4, 7, 11):
         if win - win // 2 >= min(w, h):
             continue
         gpu_ctx.min_filter_to(src, dst, w, h, d, re, win)
