@@ -128,8 +128,8 @@ def main():
                     "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic.get(name), "avg_ms": round(secs * 1e3, 4),
                     "algorithmic_bytes": int(nbytes)}
-        ka = roof("fused_rawbox_h_kernel", bytes_a, ta)
-        kb = roof("fused_boxv_wta_kernel", bytes_b, tb)
+        ka = roof("fused_rawbox_h_lds_kernel", bytes_a, ta)
+        kb = roof("fused_boxv_wta_vpl_kernel", bytes_b, tb)
         dominant = ka if ta >= tb else kb
         fused = roof("fused pair (pass A + pass B)", bytes_fused, ta + tb)
 
