@@ -131,6 +131,28 @@ int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems,
 int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
               size_t row_elems, int32_t *d_disp, float *d_best);
 
+/* ---- along-d stages behind the aggregated DSI (disp_step < 1 / refine_subpix runs) ---- */
+
+/* AggrSubPixelFit (StcAggregate.cpp:66-132): d_src -> d_dst (distinct), plus m_sub_pixel_min and
+ * m_sub_pixel_cert, all [h][row_elems]; match_outside marks invalid levels (:98-101). */
+int smhip_subpixel_fit(smhip_ctx *ctx, const float *d_src, float *d_dst, float *d_min,
+                       float *d_cert, int w, int h, int n_bands, size_t row_elems,
+                       float match_outside);
+
+/* AggrCollapse (StcAggregate.cpp:134-230): n_bands1 fractional levels (step 1/df) -> n_bands2 =
+ * (n_bands1 - 1)/df + 1 integer levels; d_min1 is m_sub_pixel_min or NULL when aggr_subpixel is
+ * off; disp_step is the fractional step before the collapse (:186,:191). */
+int smhip_collapse(smhip_ctx *ctx, const float *d_cost1, const float *d_min1, int w, int h,
+                   int n_bands1, size_t row_elems1, int df, int n_bands2, size_t row_elems2,
+                   float disp_step, float *d_cost2, float *d_min2);
+
+/* Refine (StcRefine.cpp:28-100): d_fdisp = disp_step * d + disp_min, then mode 1: + the
+ * offsets of m_sub_pixel_min (:50-68), mode 2: + the parabola fit through the winner's
+ * neighbours in d_cost (:75-98); mode 0 or n_bands < 3: ScaleAndOffset only. */
+int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, const float *d_min,
+                 int w, int h, int n_bands, size_t row_elems, float disp_step, float disp_min,
+                 int mode, float *d_fdisp);
+
 /* ---- fused path: RawCosts -> AggrBox (1 iteration) -> PadCosts -> OptWTA ----
  * Same results as the four stage calls, without materialising the raw or the aggregated
  * DSI.  Works on the disparity slab [d_first, d_first + d_count) of the D = p->disp_n

@@ -28,6 +28,7 @@ class Params(C.Structure):
         ("opt_smoothness", C.c_float), ("opt_grad_thresh", C.c_float),
         ("opt_grad_penalty", C.c_float),
         ("disp_step", C.c_float), ("disp_scale", C.c_float),
+        ("aggr_subpixel", C.c_int), ("aggr_collapse", C.c_int), ("refine_subpix", C.c_int),
     ]
 
 
@@ -51,6 +52,7 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
         diff_lambda=0.15, diff_beta=0.5,
         opt_smoothness=1.0, opt_grad_thresh=5.0, opt_grad_penalty=1.0,
         disp_step=float(step), disp_scale=disp_scale,
+        aggr_subpixel=0, aggr_collapse=0, refine_subpix=0,
     )
     for k, v in kw.items():
         if not hasattr(p, k):
@@ -96,6 +98,15 @@ def lib():
         L.smo_depth_image.argtypes = [i32, C.c_int, pp, u8]
         L.smo_compute_correspondence.restype = C.c_float
         L.smo_compute_correspondence.argtypes = [u8, u8, C.c_long, pp, i32, fp, u8]
+        L.smo_compute_correspondence_f.restype = C.c_float
+        L.smo_compute_correspondence_f.argtypes = [u8, u8, C.c_long, pp, i32, fp, u8, fp]
+        L.smo_subpixel_fit.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float]
+        L.smo_collapse.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                   C.c_long, C.c_float, fp, fp]
+        L.smo_refine.argtypes = [fp, fp, i32, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float,
+                                 C.c_int, C.c_int, fp]
+        for name in ("smo_subpixel_fit", "smo_collapse", "smo_refine"):
+            getattr(L, name).restype = None
         for name in ("smo_raw_costs", "smo_box_filter", "smo_min_filter", "smo_convolve_14641",
                      "smo_diffusion_iter", "smo_pad_costs", "smo_wta", "smo_aggregate",
                      "smo_depth_image"):
@@ -202,3 +213,49 @@ def compute_correspondence(ref, mtc, p):
     e = lib().smo_compute_correspondence(_u8(ref), _u8(mtc), w * b, C.byref(p),
                                          _i32(disp), _fp(best), _u8(depth))
     return disp, best, depth, float(e)
+
+
+def compute_correspondence_f(ref, mtc, p):
+    """As compute_correspondence, plus m_float_disparity: (disp, best, depth, energy, fdisp)."""
+    ref, mtc = _img(ref), _img(mtc)
+    h, w, b = ref.shape
+    assert (w, h, b) == (p.width, p.height, p.n_bands) and mtc.shape == ref.shape
+    disp = np.empty((h, w), np.int32)
+    best = np.empty((h, w), np.float32)
+    depth = np.empty((h, w), np.uint8)
+    fdisp = np.empty((h, w), np.float32)
+    e = lib().smo_compute_correspondence_f(_u8(ref), _u8(mtc), w * b, C.byref(p),
+                                           _i32(disp), _fp(best), _u8(depth), _fp(fdisp))
+    return disp, best, depth, float(e), fdisp
+
+
+def subpixel_fit(cost, outside):
+    """AggrSubPixelFit: returns (cost, mind, cert)."""
+    c = np.array(cost, dtype=np.float32, order="C", copy=True)
+    h, w, d = c.shape
+    mind, cert = np.empty_like(c), np.empty_like(c)
+    lib().smo_subpixel_fit(_fp(c), _fp(mind), _fp(cert), w, h, d, w * d, outside)
+    return c, mind, cert
+
+
+def collapse(cost, mind, df, disp_step):
+    """AggrCollapse: returns (cost2, mind2) with (D - 1) // df + 1 levels."""
+    c = np.ascontiguousarray(cost, np.float32)
+    h, w, d = c.shape
+    d2 = (d - 1) // df + 1
+    m = np.ascontiguousarray(mind, np.float32) if mind is not None else None
+    c2, m2 = np.empty((h, w, d2), np.float32), np.empty((h, w, d2), np.float32)
+    lib().smo_collapse(_fp(c), _fp(m) if m is not None else None, w, h, d, w * d, df, d2, w * d2,
+                       disp_step, _fp(c2), _fp(m2))
+    return c2, m2
+
+
+def refine(cost, mind, disp, step, disp_min, mode):
+    c = np.ascontiguousarray(cost, np.float32)
+    h, w, d = c.shape
+    m = np.ascontiguousarray(mind, np.float32) if mind is not None else None
+    dd = np.ascontiguousarray(disp, np.int32)
+    out = np.empty((h, w), np.float32)
+    lib().smo_refine(_fp(c), _fp(m) if m is not None else None, _i32(dd), w, h, d, w * d, step,
+                     disp_min, mode, _fp(out))
+    return out

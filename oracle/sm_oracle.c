@@ -489,23 +489,172 @@ void smo_depth_image(const int32_t *disp, int n, const smo_params *p, uint8_t *d
     }
 }
 
+/* StcAggregate.cpp:66-132: every level of every pixel gets the interpolated minimum of the
+ * parabola through (d-1, d, d+1) or the lower half-value; c0/c1/c2 are the values before the
+ * fit (the loop reads cost[d+1] before it overwrites cost[d]). */
+void smo_subpixel_fit(float *cost, float *mind, float *cert, int w, int h, int nb,
+                      long row_elems, float outside)
+{
+    for (int y = 0; y < h; y++) {
+        float *c = cost + (size_t)y * row_elems;
+        float *mn = mind + (size_t)y * row_elems;
+        float *ce = cert + (size_t)y * row_elems;
+        for (int x = 0, l = 0; x < w; x++, l += nb) {
+            float c0 = c[l], c1 = c[l], c2 = c[l];
+            for (int d = 0; d < nb; d++) {
+                c0 = c1, c1 = c2, c2 = c[l + imin(nb - 1, d + 1)];
+                mn[l + d] = 0.0f;
+                ce[l + d] = 0.0f;
+                if (c0 == outside || c1 == outside || c2 == outside)
+                    continue;
+                if (c1 <= c0 && c1 <= c2) {
+                    float a = 0.5 * (c0 - 2.0 * c1 + c2);          /* :107, double arithmetic */
+                    float b = 0.5 * (c2 - c0);
+                    if (a <= 0.0 || a < 0.5 * fabs(b))
+                        continue;
+                    float dn = -0.5 * (b / a);
+                    float cn = c1 + 0.5 * b * dn;
+                    if (cn < 0.0)
+                        continue;
+                    c[l + d] = (0.0f > cn) ? 0.0f : cn;               /* __max(0.0f, cn), Image.h:50 */
+                    mn[l + d] = dn;
+                    ce[l + d] = a;
+                } else {
+                    c[l + d] = 0.5f * (c1 + (c0 < c2 ? c0 : c2));
+                    mn[l + d] = (c0 < c2) ? -0.5f : 0.5f;
+                    ce[l + d] = 0.0f;
+                }
+            }
+        }
+    }
+}
+
+/* StcAggregate.cpp:134-230: df fractional levels -> one integer level; mind1 NULL when
+ * aggr_subpixel is off.  nb1 = levels before, nb2 = (disp_max - disp_min) + 1. */
+void smo_collapse(const float *cost1, const float *mind1, int w, int h, int nb1, long row_elems1,
+                  int df, int nb2, long row_elems2, float disp_step, float *cost2, float *mind2)
+{
+    int df2 = df / 2;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const float *c1 = cost1 + (size_t)y * row_elems1 + (size_t)x * nb1;
+            const float *m1 = mind1 ? mind1 + (size_t)y * row_elems1 + (size_t)x * nb1 : NULL;
+            float *c2 = cost2 + (size_t)y * row_elems2 + (size_t)x * nb2;
+            float *m2 = mind2 + (size_t)y * row_elems2 + (size_t)x * nb2;
+            for (int d1 = 0, d2 = 0; d2 < nb2; d2++) {
+                int d1_end = imin(nb1, d2 * df + df - df2);
+                int d1_bst = d1;
+                for (d1 = d1 + 1; d1 < d1_end; d1++)
+                    if (c1[d1] < c1[d1_bst])
+                        d1_bst = d1;
+                c2[d2] = c1[d1_bst];
+                if (m1)
+                    m2[d2] = (m1[d1_bst] + d1_bst - d2 * df) * disp_step;   /* :186 */
+                else
+                    m2[d2] = (d1_bst - d2 * df) * disp_step;                /* :191 */
+            }
+        }
+}
+
+/* StcRefine.cpp:28-100.  mode 0: ScaleAndOffset only; 1: offsets from mind (:50-68);
+ * 2: parabola through the winner's neighbours (:75-98). */
+void smo_refine(const float *cost, const float *mind, const int32_t *disp, int w, int h, int nb,
+                long row_elems, float step, int disp_min, int mode, float *fdisp)
+{
+    float d_offset = (float)disp_min;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * w + x;
+            int dw = disp[i];
+            /* ScaleAndOffset int -> float, Convert.cpp:31-40 */
+            fdisp[i] = (step != 1.0f || d_offset != 0.0f) ? (float)dw * step + d_offset : (float)dw;
+            if (mode == 0 || nb < 3)
+                continue;
+            size_t l = (size_t)y * row_elems + (size_t)x * nb;
+            if (mode == 1) {
+                float x0 = mind[l + dw];
+                fdisp[i] = step * (dw + x0) + d_offset;
+                continue;
+            }
+            int d_min = dw + (dw == 0) - (dw == nb - 1);
+            float c0 = cost[l + d_min - 1], c1 = cost[l + d_min], c2 = cost[l + d_min + 1];
+            float a = 0.5 * (c0 - 2.0 * c1 + c2);
+            float b = 0.5 * (c2 - c0);
+            if (a <= 0.0 || a < 0.5 * fabs(b))
+                continue;
+            float x0 = -0.5 * b / a;
+            fdisp[i] = step * (d_min + x0) + d_offset;
+        }
+}
+
+/* StereoMatcher.cpp:177 via Convert.cpp:25-53: float -> uchar, clip, truncate */
+void smo_depth_from_float(const float *fdisp, int n, const smo_params *p, uint8_t *depth)
+{
+    float offset = (float)(-p->disp_min * p->disp_scale + 0.5);
+    for (int i = 0; i < n; i++) {
+        float v = fdisp[i];
+        if (p->disp_scale != 1.0f || offset != 0.0f)
+            v = v * p->disp_scale + offset;
+        v = v < 0.0f ? 0.0f : v;
+        v = v > 255.0f ? 255.0f : v;
+        depth[i] = (uint8_t)v;
+    }
+}
+
 float smo_compute_correspondence(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
                                  const smo_params *p, int32_t *disp, float *best_cost,
                                  uint8_t *depth)
 {
-    int w = p->width, h = p->height;
-    long row_elems = (long)w * p->disp_n;
+    return smo_compute_correspondence_f(ref, mtc, img_row_bytes, p, disp, best_cost, depth, NULL);
+}
+
+float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
+                                   const smo_params *p, int32_t *disp, float *best_cost,
+                                   uint8_t *depth, float *fdisp)
+{
+    int w = p->width, h = p->height, nd = p->disp_n;
+    long row_elems = (long)w * nd;
+    size_t n_pix = (size_t)w * h;
     float *cost = malloc((size_t)row_elems * h * sizeof(float));
-    int32_t *d = disp ? disp : malloc((size_t)w * h * sizeof(int32_t));
+    float *mind = NULL;
+    int32_t *d = disp ? disp : malloc(n_pix * sizeof(int32_t));
+    float *fd = fdisp ? fdisp : malloc(n_pix * sizeof(float));
+    float step = p->disp_step;
 
     smo_raw_costs(ref, mtc, img_row_bytes, p, cost, row_elems);
     smo_aggregate(cost, row_elems, p);
-    smo_wta(cost, w, h, p->disp_n, row_elems, d, best_cost);
-    float energy = smo_final_energy(cost, row_elems, d, ref, img_row_bytes, p);
+    if (p->aggr_subpixel) {                              /* StcAggregate.cpp:368-385 */
+        mind = malloc((size_t)row_elems * h * sizeof(float));
+        float *cert = malloc((size_t)row_elems * h * sizeof(float));
+        smo_subpixel_fit(cost, mind, cert, w, h, nd, row_elems, smo_match_outside(p));
+        free(cert);
+    }
+    if (p->aggr_collapse && step < 1.0f) {               /* :388-400, :137-146 */
+        int df = p->disp_den;
+        int nd2 = (nd - 1) / df + 1;                     /* (disp_max - disp_min) + 1 */
+        long re2 = (long)w * nd2;
+        float *cost2 = malloc((size_t)re2 * h * sizeof(float));
+        float *mind2 = malloc((size_t)re2 * h * sizeof(float));
+        smo_collapse(cost, mind, w, h, nd, row_elems, df, nd2, re2, p->disp_step, cost2, mind2);
+        free(cost);
+        free(mind);
+        cost = cost2; mind = mind2; nd = nd2; row_elems = re2; step = 1.0f;
+    }
+    smo_wta(cost, w, h, nd, row_elems, d, best_cost);
+    smo_params q = *p;
+    q.disp_n = nd;
+    float energy = smo_final_energy(cost, row_elems, d, ref, img_row_bytes, &q);
+    int mode = 0;                                        /* StcRefine.cpp:42-68 */
+    if (p->refine_subpix && nd >= 3)
+        mode = (p->aggr_subpixel || (p->aggr_collapse && p->disp_step < 1.0f)) ? 1 : 2;
+    smo_refine(cost, mind, d, w, h, nd, row_elems, step, p->disp_min, mode, fd);
     if (depth)
-        smo_depth_image(d, w * h, p, depth);
+        smo_depth_from_float(fd, w * h, p, depth);
     if (!disp)
         free(d);
+    if (!fdisp)
+        free(fd);
+    free(mind);
     free(cost);
     return energy;
 }

@@ -49,6 +49,8 @@ typedef struct smo_params {
     float opt_smoothness, opt_grad_thresh, opt_grad_penalty;
     /* depth-map scaling, StereoMatcher.cpp:177 */
     float disp_step, disp_scale;
+    /* sub-pixel stages, StereoParameters.h:118-120,179 */
+    int aggr_subpixel, aggr_collapse, refine_subpix;
 } smo_params;
 
 /* StcRawCosts.cpp:364-367 */
@@ -80,7 +82,7 @@ void smo_pad_costs(float *cost, long row_elems, const smo_params *p);
 void smo_wta(const float *cost, int w, int h, int nb, long row_elems,
              int32_t *disp, float *best_cost);
 
-/* StcAggregate.cpp:255-365 (no sub-pixel fit / collapse) */
+/* StcAggregate.cpp:255-365 (sub-pixel fit / collapse: separate calls below) */
 void smo_aggregate(float *cost, long row_elems, const smo_params *p);
 
 /* StcOptimize.cpp:84-156 + StcGraphCut.cpp:36-75: data + smoothness energy */
@@ -96,6 +98,26 @@ void smo_depth_image(const int32_t *disp, int n, const smo_params *p, uint8_t *d
 float smo_compute_correspondence(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
                                  const smo_params *p, int32_t *disp, float *best_cost,
                                  uint8_t *depth);
+
+/* StcAggregate.cpp:66-132 (in place; mind/cert: same shape as cost) */
+void smo_subpixel_fit(float *cost, float *mind, float *cert, int w, int h, int nb,
+                      long row_elems, float outside);
+
+/* StcAggregate.cpp:134-230 (mind1 NULL when aggr_subpixel is off) */
+void smo_collapse(const float *cost1, const float *mind1, int w, int h, int nb1, long row_elems1,
+                  int df, int nb2, long row_elems2, float disp_step, float *cost2, float *mind2);
+
+/* StcRefine.cpp:28-100; mode 0 plain, 1 offsets from mind, 2 parabola fit at the winner */
+void smo_refine(const float *cost, const float *mind, const int32_t *disp, int w, int h, int nb,
+                long row_elems, float step, int disp_min, int mode, float *fdisp);
+
+/* StereoMatcher.cpp:177 */
+void smo_depth_from_float(const float *fdisp, int n, const smo_params *p, uint8_t *depth);
+
+/* the same pipeline, also returning m_float_disparity (fdisp may be NULL) */
+float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
+                                   const smo_params *p, int32_t *disp, float *best_cost,
+                                   uint8_t *depth, float *fdisp);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,7 @@ SYMBOLS = [
     "smhip_convolve_14641", "smhip_convolve_14641_to",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
+    "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
 ]
 
 
@@ -97,6 +98,9 @@ def load():
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_keys_decode.argtypes = [vp, vp, ci, ci, vp, vp]
     L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
+    L.smhip_subpixel_fit.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, sz, cf]
+    L.smhip_collapse.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, ci, sz, cf, vp, vp]
+    L.smhip_refine.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, vp]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
@@ -250,6 +254,19 @@ class Context:
     def fused_box_wta(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
         self._chk(self.L.smhip_fused_box_wta(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
                                              C.byref(p), window, _ptr(d_disp), _ptr(d_best)))
+
+    def subpixel_fit(self, d_src, d_dst, d_min, d_cert, w, h, nb, row_elems, match_outside):
+        self._chk(self.L.smhip_subpixel_fit(self.h, _ptr(d_src), _ptr(d_dst), _ptr(d_min), _ptr(d_cert),
+                                            w, h, nb, row_elems, match_outside))
+
+    def collapse(self, d_cost1, d_min1, w, h, nb1, row_elems1, df, nb2, row_elems2, disp_step,
+                 d_cost2, d_min2):
+        self._chk(self.L.smhip_collapse(self.h, _ptr(d_cost1), _ptr(d_min1), w, h, nb1, row_elems1, df,
+                                        nb2, row_elems2, disp_step, _ptr(d_cost2), _ptr(d_min2)))
+
+    def refine(self, d_disp, d_cost, d_min, w, h, nb, row_elems, disp_step, disp_min, mode, d_fdisp):
+        self._chk(self.L.smhip_refine(self.h, _ptr(d_disp), _ptr(d_cost), _ptr(d_min), w, h, nb,
+                                      row_elems, disp_step, disp_min, mode, _ptr(d_fdisp)))
 
     def profile_begin(self, max_calls):
         self._chk(self.L.smhip_profile_begin(self.h, max_calls))

@@ -1,5 +1,5 @@
 // StereoMatcher.cpp -- stage sequencing of the reference (StereoMatcher.cpp:38-181,
-// StcAggregate.cpp:255-365, StcOptimize.cpp:162-280, StcRefine.cpp:28-39) over the C-ABI.
+// StcAggregate.cpp:66-230, 255-400, StcOptimize.cpp:162-280, StcRefine.cpp:28-100) over the C-ABI.
 #include "StereoMatcher.h"
 #include "Error.h"
 #include <cmath>
@@ -241,8 +241,55 @@ void CStereoMatcher::Aggregate()
         AggrMin();
     }
     PadCosts();
-    if (aggr_subpixel || aggr_collapse)
-        throw CError("CStereoMatcher::Aggregate(): sub-pixel fit / collapse are not on the device path");
+    m_have_mind = false;
+    if (aggr_subpixel) {                                      // StcAggregate.cpp:368-385
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- sub-pixel fit\n");
+        AggrSubPixelFit();
+    }
+    if (aggr_collapse) {                                      // :388-400
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- collapse to integral DSI\n");
+        AggrCollapse();
+    }
+}
+
+void CStereoMatcher::AggrSubPixelFit()
+{
+    size_t bytes = m_row_elems * m_mp.height * sizeof(float);
+    DeviceBuffer(B_COST2, bytes);
+    DeviceBuffer(B_MIND, bytes);
+    DeviceBuffer(B_CERT, bytes);
+    Check(smhip_subpixel_fit(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                             (float *)m_dev[B_MIND], (float *)m_dev[B_CERT], m_mp.width, m_mp.height,
+                             m_disp_n, m_row_elems, m_match_outside));
+    SwapCost();
+    m_have_mind = true;
+}
+
+void CStereoMatcher::AggrCollapse()
+{
+    if (m_disp_step >= 1.0f)
+        return;                                               // StcAggregate.cpp:137-138
+    int df = int(m_disp_step_inv + 0.5);
+    if (df != m_disp_step_inv)
+        throw CError("AggrCollapse:  disparity step %g is not a pure fraction", m_disp_step);
+    int n2 = (disp_max - disp_min) + 1;
+    size_t re2 = (size_t)m_mp.width * n2;
+    size_t bytes2 = re2 * m_mp.height * sizeof(float);
+    // collapsed cost and offsets go to the spare slots, then take the places of m_cost / m_sub_pixel_min
+    DeviceBuffer(B_COST2, bytes2);
+    DeviceBuffer(B_CERT, bytes2);
+    Check(smhip_collapse(m_ctx, (const float *)m_dev[B_COST], m_have_mind ? (const float *)m_dev[B_MIND] : nullptr,
+                         m_mp.width, m_mp.height, m_disp_n, m_row_elems, df, n2, re2, disp_step,
+                         (float *)m_dev[B_COST2], (float *)m_dev[B_CERT]));
+    SwapCost();
+    std::swap(m_dev[B_MIND], m_dev[B_CERT]);
+    std::swap(m_dev_bytes[B_MIND], m_dev_bytes[B_CERT]);
+    m_have_mind = true;
+    m_disp_step = m_disp_step_inv = 1.0f;                     // :145-146
+    m_disp_n = n2;
+    m_row_elems = re2;
 }
 
 void CStereoMatcher::OptWTA()
@@ -313,17 +360,32 @@ void CStereoMatcher::ComputeEnergy(float &denergy, float &nenergy)
 
 void CStereoMatcher::Refine()
 {
-    // m_float_disparity = disp * step + disp_min (StcRefine.cpp:34-39 via Convert.cpp:31-52)
     float d_offset = (float)disp_min;
-    bool scale_offset = (m_disp_step != 1.0f) || (d_offset != 0.0f);
-    for (int y = 0; y < m_mp.height; y++) {
-        const int *src = m_disparity.Row(y);
-        float *dst = m_float_disparity.Row(y);
-        for (int x = 0; x < m_mp.width; x++)
-            dst[x] = scale_offset ? src[x] * m_disp_step + d_offset : (float)src[x];
+    if (m_used_fused || !refine_subpix || m_disp_n < 3) {
+        // m_float_disparity = disp * step + disp_min (StcRefine.cpp:34-43 via Convert.cpp:31-52)
+        bool scale_offset = (m_disp_step != 1.0f) || (d_offset != 0.0f);
+        for (int y = 0; y < m_mp.height; y++) {
+            const int *src = m_disparity.Row(y);
+            float *dst = m_float_disparity.Row(y);
+            for (int x = 0; x < m_mp.width; x++)
+                dst[x] = scale_offset ? src[x] * m_disp_step + d_offset : (float)src[x];
+        }
+        return;
     }
-    if (refine_subpix)
-        throw CError("CStereoMatcher::Refine(): sub-pixel refinement is not on the device path");
+    // sub-pixel fit on the resident DSI: offsets of the aggregation-stage fit (:50-68) or a
+    // parabola through the winner's neighbours (:75-98)
+    bool from_fit = aggr_subpixel || (aggr_collapse && disp_step < 1.0f);
+    if (from_fit && !m_have_mind)
+        throw CError("CStereoMatcher::Refine(): no sub-pixel minima available");
+    if (!from_fit && verbose >= eVerboseProgress)
+        fprintf(stderr, "- refining: subpixel parabola fit\n");
+    size_t wbytes = (size_t)m_mp.width * 4;
+    DeviceBuffer(B_FDISP, wbytes * m_mp.height);
+    Check(smhip_refine(m_ctx, (const int32_t *)m_dev[B_DISP], (const float *)m_dev[B_COST],
+                       from_fit ? (const float *)m_dev[B_MIND] : nullptr, m_mp.width, m_mp.height, m_disp_n,
+                       m_row_elems, m_disp_step, d_offset, from_fit ? 1 : 2, (float *)m_dev[B_FDISP]));
+    Check(smhip_memcpy2d_d2h(m_ctx, m_float_disparity.Data(), m_float_disparity.RowBytes(), m_dev[B_FDISP],
+                             wbytes, wbytes, m_mp.height));
 }
 
 void CStereoMatcher::Evaluate()

@@ -6,6 +6,7 @@
 #include "smhip_stencil.h"
 #include "smhip_subpix.h"
 #include "smhip_stage.h"
+#include "smhip_refine.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -671,6 +672,68 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
         smk::wta_thread_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
             d_cost, w, h, nb, row_elems, d_disp, d_best);
     }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_subpixel_fit(smhip_ctx *ctx, const float *d_src, float *d_dst, float *d_min, float *d_cert,
+                       int w, int h, int nb, size_t row_elems, float match_outside)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_src, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_dst || !d_min || !d_cert || d_dst == d_src)
+        return fail(SMHIP_EINVAL, "AggrSubPixelFit: needs distinct source, destination, min and cert buffers");
+    dim3 grid((w * nb + 255) / 256, h);
+    smk::subpixel_fit_kernel<<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, d_min, d_cert, w, nb, row_elems,
+                                                           match_outside);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_collapse(smhip_ctx *ctx, const float *d_cost1, const float *d_min1, int w, int h, int nb1,
+                   size_t row_elems1, int df, int nb2, size_t row_elems2, float disp_step,
+                   float *d_cost2, float *d_min2)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost1, w, h, nb1, row_elems1);
+    if (rc) return rc;
+    rc = check_dsi(d_cost2, w, h, nb2, row_elems2);
+    if (rc) return rc;
+    if (!d_min2)
+        return fail(SMHIP_EINVAL, "AggrCollapse: null output");
+    if (df < 2 || (nb1 - 1) % df != 0 || nb2 != (nb1 - 1) / df + 1)   // StcAggregate.cpp:139-146
+        return fail(SMHIP_EINVAL, "AggrCollapse: %d levels at step 1/%d do not collapse to %d", nb1, df, nb2);
+    dim3 grid((w * nb2 + 255) / 256, h);
+    smk::collapse_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost1, d_min1, w, nb1, row_elems1, df, nb2,
+                                                       row_elems2, disp_step, d_cost2, d_min2);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, const float *d_min, int w,
+                 int h, int nb, size_t row_elems, float disp_step, float disp_min, int mode,
+                 float *d_fdisp)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_disp || !d_fdisp || w < 1 || h < 1 || nb < 1)
+        return fail(SMHIP_EINVAL, "Refine: bad arguments");
+    if (mode < 0 || mode > 2)
+        return fail(SMHIP_EINVAL, "Refine: unknown mode %d", mode);
+    if (mode == 2) {
+        rc = check_dsi(d_cost, w, h, nb, row_elems);
+        if (rc) return rc;
+    }
+    if (mode == 1) {
+        rc = check_dsi(d_min, w, h, nb, row_elems);
+        if (rc) return rc;
+    }
+    long n_pix = (long)w * h;
+    smk::refine_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        d_cost, d_min, d_disp, w, h, nb, row_elems, disp_step, disp_min, mode, d_fdisp);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

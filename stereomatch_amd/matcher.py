@@ -119,19 +119,25 @@ class StereoMatcher(StereoParameters):
         self.d_disp = self._buf("disp", w * h * 4)
         self.d_best = self._buf("best", w * h * 4)
         self.used_fused = self._fusable()
+        self.m_disp_step = np.float32(self.disp_step)
+        self.d_mind = None
         if self.used_fused:
             c.fused_box_wta(self.d_ref, self.d_mtc, self.m_pitch, self.m_params,
                             self.aggr_window_size, self.d_disp, self.d_best)
+            disp = c.download(self.d_disp, (h, w), np.int32)
+            self.m_float_disparity = self._scale_and_offset(disp)
         else:
             self.RawCosts()
             self.Aggregate()
             self.Optimize()
-        disp = c.download(self.d_disp, (h, w), np.int32)
+            disp = c.download(self.d_disp, (h, w), np.int32)
+            self.m_float_disparity = self.Refine()
         best = c.download(self.d_best, (h, w), np.float32)
-        return disp, best, self.Refine(disp)
+        return disp, best, self._depth_image(self.m_float_disparity)
 
     def RawCosts(self):  # StcRawCosts.cpp:229
         p = self.m_params
+        self.m_disp_n = p.disp_n
         self.m_row_elems = p.width * p.disp_n
         self.d_cost = self._buf("cost", self.m_row_elems * p.height * 4)
         self.ctx.raw_costs(self.d_ref, self.d_mtc, self.m_pitch, p, self.d_cost, self.m_row_elems)
@@ -166,20 +172,64 @@ class StereoMatcher(StereoParameters):
             self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
             self.d_cost = other
         c.pad_costs(self.d_cost, re, p)                                  # :365
+        if self.aggr_subpixel:                                           # :368-385
+            self.AggrSubPixelFit()
+        if self.aggr_collapse:                                           # :388-400
+            self.AggrCollapse()
+
+    def AggrSubPixelFit(self):  # StcAggregate.cpp:66-132
+        p, c = self.m_params, self.ctx
+        nbytes = self.m_row_elems * p.height * 4
+        other = self._buf("cost2", nbytes)
+        self.d_mind = self._buf("mind", nbytes)
+        self.d_cert = self._buf("cert", nbytes)
+        c.subpixel_fit(self.d_cost, other, self.d_mind, self.d_cert, p.width, p.height, self.m_disp_n,
+                       self.m_row_elems, self.m_match_outside)
+        self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+        self.d_cost = other
+
+    def AggrCollapse(self):  # StcAggregate.cpp:134-230
+        if self.m_disp_step >= 1.0:
+            return
+        p, c = self.m_params, self.ctx
+        df = self.m_disp_den
+        n2 = (self.disp_max - self.disp_min) + 1
+        re2 = p.width * n2
+        cost2 = self._buf("cost_c", re2 * p.height * 4)
+        mind2 = self._buf("mind_c", re2 * p.height * 4)
+        c.collapse(self.d_cost, self.d_mind, p.width, p.height, self.m_disp_n, self.m_row_elems, df, n2,
+                   re2, float(self.m_disp_step), cost2, mind2)
+        self.d_cost, self.d_mind = cost2, mind2          # :227-229
+        self.m_disp_n, self.m_row_elems, self.m_disp_step = n2, re2, np.float32(1.0)
 
     def Optimize(self):  # StcOptimize.cpp:162-280, WTA only
         if self.opt_fn != eWTA:
             raise ValueError("CStereoMatcher::Optimize(): only opt_fn = eWTA is on the device path")
         p = self.m_params
-        self.ctx.wta(self.d_cost, p.width, p.height, p.disp_n, self.m_row_elems, self.d_disp,
+        self.ctx.wta(self.d_cost, p.width, p.height, self.m_disp_n, self.m_row_elems, self.d_disp,
                      self.d_best)
 
-    def Refine(self, disp):  # StcRefine.cpp:34-39 + StereoMatcher.cpp:177 (Convert.cpp:25-53)
+    def Refine(self):  # StcRefine.cpp:28-100, on the resident DSI
+        p, c = self.m_params, self.ctx
+        mode = 0
+        if self.refine_subpix and self.m_disp_n >= 3:
+            from_fit = self.aggr_subpixel or (self.aggr_collapse and np.float32(self.disp_step) < 1.0)
+            mode = 1 if from_fit else 2
+        d_f = self._buf("fdisp", p.width * p.height * 4)
+        c.refine(self.d_disp, self.d_cost, self.d_mind if mode == 1 else None, p.width, p.height,
+                 self.m_disp_n, self.m_row_elems, float(self.m_disp_step), float(self.disp_min), mode, d_f)
+        return c.download(d_f, (p.height, p.width), np.float32)
+
+    def _scale_and_offset(self, disp):  # StcRefine.cpp:34-39 (Convert.cpp:31-40)
         f32 = np.float32
         d_off = f32(self.disp_min)
         fd = disp.astype(f32)
-        if f32(self.disp_step) != 1.0 or d_off != 0.0:
-            fd = fd * f32(self.disp_step) + d_off
+        if f32(self.m_disp_step) != 1.0 or d_off != 0.0:
+            fd = fd * f32(self.m_disp_step) + d_off
+        return fd
+
+    def _depth_image(self, fd):  # StereoMatcher.cpp:177 (Convert.cpp:25-53)
+        f32 = np.float32
         off = f32(np.float64(f32(-self.disp_min) * f32(self.disp_scale)) + 0.5)
         v = fd
         if f32(self.disp_scale) != 1.0 or off != 0.0:
@@ -188,7 +238,7 @@ class StereoMatcher(StereoParameters):
 
     def download_cost(self):
         p = self.m_params
-        return self.ctx.download(self.d_cost, (p.height, p.width, p.disp_n), np.float32)
+        return self.ctx.download(self.d_cost, (p.height, p.width, self.m_disp_n), np.float32)
 
     def _copy(self, dst, src, nbytes):
         self.ctx.copy_d2d(dst, src, nbytes)

@@ -247,3 +247,45 @@ def test_out_of_place_filters(gpu_ctx, oracle, h, w, d, pad):
     util.assert_bit_equal(gpu_ctx.download(src, (h, re), np.float32), host, "source")
     with pytest.raises(capi.SmhipError):
         gpu_ctx.convolve_14641_to(src, src, w, h, d, re)
+
+
+@pytest.mark.parametrize("h,w,d", [(5, 9, 3), (6, 17, 16), (4, 11, 31), (3, 7, 100)])
+def test_subpixel_fit_collapse_refine(gpu_ctx, oracle, h, w, d):
+    """AggrSubPixelFit / AggrCollapse / Refine (StcAggregate.cpp:66-230, StcRefine.cpp:28-100)
+    against the oracle on random volumes with invalid levels, plateaus and ties.  The reference
+    holds no output for these stages: parity unpinned."""
+    outside = 255.0
+    rng = np.random.RandomState(70 + d)
+    c = rng.randint(0, 12, size=(h, w, d)).astype(np.float32)     # many ties and plateaus
+    f = (rng.rand(h, w, d) * 30.0).astype(np.float32)
+    c = np.where(rng.rand(h, w, d) < 0.5, f, c).astype(np.float32)
+    c[rng.rand(h, w, d) < 0.05] = outside
+    wc, wm, we = oracle.subpixel_fit(c, outside)
+    n = h * w * d * 4
+    src, dst, dmin, dcert = up(gpu_ctx, c), gpu_ctx.alloc(n), gpu_ctx.alloc(n), gpu_ctx.alloc(n)
+    gpu_ctx.subpixel_fit(src, dst, dmin, dcert, w, h, d, w * d, outside)
+    util.assert_bit_equal(gpu_ctx.download(dst, (h, w, d), np.float32), wc, "fit cost")
+    util.assert_bit_equal(gpu_ctx.download(dmin, (h, w, d), np.float32), wm, "fit min")
+    util.assert_bit_equal(gpu_ctx.download(dcert, (h, w, d), np.float32), we, "fit cert")
+    # collapse, with and without the fitted offsets
+    for df in (2, 3, 5):
+        if (d - 1) % df:
+            continue
+        d2 = (d - 1) // df + 1
+        step = float(np.float32(1.0) / np.float32(df))
+        for mind, dm in ((wm, dmin), (None, None)):
+            oc2, om2 = oracle.collapse(wc, mind, df, step)
+            c2, m2 = gpu_ctx.alloc(h * w * d2 * 4), gpu_ctx.alloc(h * w * d2 * 4)
+            gpu_ctx.collapse(dst, dm, w, h, d, w * d, df, d2, w * d2, step, c2, m2)
+            util.assert_bit_equal(gpu_ctx.download(c2, (h, w, d2), np.float32), oc2, "collapse cost")
+            util.assert_bit_equal(gpu_ctx.download(m2, (h, w, d2), np.float32), om2, "collapse min")
+    # refine in the three modes, winners from the oracle's WTA
+    disp, _ = oracle.wta(wc)
+    ddisp, fd = up(gpu_ctx, disp), gpu_ctx.alloc(h * w * 4)
+    for mode in (0, 1, 2):
+        for step, dmn in ((1.0, 0), (0.5, 3)):
+            gpu_ctx.refine(ddisp, dst, dmin, w, h, d, w * d, step, float(dmn), mode, fd)
+            util.assert_bit_equal(gpu_ctx.download(fd, (h, w), np.float32),
+                                  oracle.refine(wc, wm, disp, step, dmn, mode), "refine %d" % mode)
+    with pytest.raises(capi.SmhipError):
+        gpu_ctx.collapse(dst, dmin, w, h, d, w * d, 2, d, w * d, 0.5, dst, dmin)

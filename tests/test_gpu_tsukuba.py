@@ -81,3 +81,30 @@ def test_subpixel_step_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
     util.assert_bit_equal(disp, odisp, "disparity")
     util.assert_bit_equal(best, obest, "best cost")
     assert np.array_equal(depth, odepth.reshape(depth.shape))
+
+
+@pytest.mark.parametrize("kw", [
+    dict(refine_subpix=1, match_fn=2, aggr_window_size=9),
+    dict(aggr_subpixel=1, refine_subpix=1, match_fn=1, aggr_window_size=7),
+    dict(disp_step=0.5, aggr_subpixel=1, aggr_collapse=1, refine_subpix=1, match_interval=1),
+    dict(disp_step=0.25, aggr_collapse=1, refine_subpix=1, match_fn=2, match_max=20),
+    dict(disp_step=0.5, aggr_collapse=1, aggr_fn=2, aggr_iter=2),
+    dict(disp_step=0.5, refine_subpix=1, aggr_minfilter=3),
+])
+def test_subpixel_stages_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
+    """AggrSubPixelFit / AggrCollapse / Refine end to end, including the float disparities
+    (no reference output for these settings: parity unpinned)."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    seq = dict(util.TSUKUBA_SEQ)
+    p = oracle.make_params(w, h, b, **seq, **kw)
+    odisp, obest, odepth, _, ofd = oracle.compute_correspondence_f(ref, mtc, p)
+    m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+    disp, best, depth = m.ComputeCorrespondence(ref, mtc)
+    assert not m.used_fused
+    util.assert_bit_equal(disp, odisp, "disparity")
+    util.assert_bit_equal(best, obest, "best cost")
+    util.assert_bit_equal(m.m_float_disparity, ofd, "float disparity")
+    assert np.array_equal(depth, odepth)
+    if kw.get("refine_subpix") and (kw.get("aggr_subpixel") or not kw.get("aggr_collapse")):
+        assert np.any(m.m_float_disparity != np.round(m.m_float_disparity * 4) / 4)
