@@ -48,3 +48,49 @@ def all_reduce_min_keys(keys_tensor, group=None):
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(keys_tensor, op=dist.ReduceOp.MIN, group=group)
     return keys_tensor
+
+
+class KeyReducePipeline:
+    """Overlaps the key all-reduce of frame i with the slab computation of frame i + 1.
+
+    `produce(buf, frame)` enqueues the slab computation that fills key buffer `buf`;
+    `consume(buf, frame)` enqueues whatever reads the merged keys (e.g. smhip_keys_decode).
+    Two key buffers alternate.  The all-reduce is issued asynchronously right after
+    `produce`; the previous frame's reduce is waited for (a stream wait under RCCL, no host
+    block) and consumed only after the current frame's compute has been enqueued, so xGMI
+    traffic runs under the next frame's kernels.  Stream order on the compute stream --
+    produce(i), wait(i-1), consume(i-1), produce(i+1), ... -- also guarantees a buffer is not
+    rewritten before its consumer ran.  Call flush() after the last frame.
+    """
+
+    def __init__(self, key_buffers, produce, consume, group=None):
+        if len(key_buffers) != 2:
+            raise ValueError("KeyReducePipeline needs exactly two key buffers")
+        self.bufs, self.produce, self.consume, self.group = key_buffers, produce, consume, group
+        self.n = 0
+        self.pending = None
+
+    def _reduce_async(self, buf):
+        import torch.distributed as dist
+        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
+        return None
+
+    def _drain(self):
+        if self.pending is not None:
+            work, buf, frame = self.pending
+            self.pending = None
+            if work is not None:
+                work.wait()
+            self.consume(buf, frame)
+
+    def submit(self, frame):
+        buf = self.bufs[self.n & 1]
+        self.n += 1
+        self.produce(buf, frame)
+        work = self._reduce_async(buf)
+        self._drain()
+        self.pending = (work, buf, frame)
+
+    def flush(self):
+        self._drain()

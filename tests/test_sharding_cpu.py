@@ -81,3 +81,62 @@ def test_gloo_slab_merge_equals_oracle_wta(oracle, tmp_path, world):
     d, b = sharding.decode_keys(np.load(op).T)
     assert np.array_equal(d, want_d)
     util.assert_bit_equal(b, want_b, "merged best cost")
+
+
+def _pipeline_worker(rank, world, port, cost_path, out_path, n_frames):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cost = np.load(cost_path)                       # [F, H, W, D]: one DSI per frame
+    D = cost.shape[3]
+    d0, n = sharding.slab_bounds(D, world, rank)
+    got, log = {}, []
+
+    def produce(buf, f):
+        slab = cost[f][:, :, d0:d0 + n]
+        local = np.argmin(slab, axis=2)
+        best = np.take_along_axis(slab, local[..., None], axis=2)[..., 0]
+        buf.copy_(torch.from_numpy(sharding.encode_keys(best, local + d0).T.copy()))
+        log.append(("p", f))
+
+    def consume(buf, f):
+        got[f] = buf.numpy().copy()
+        log.append(("c", f))
+
+    h, w = cost.shape[1:3]
+    bufs = [torch.empty((w, h), dtype=torch.int64) for _ in range(2)]
+    pipe = sharding.KeyReducePipeline(bufs, produce, consume)
+    for f in range(n_frames):
+        pipe.submit(f)
+    pipe.flush()
+    # frame f is consumed after frame f + 1 was produced (the overlap), the last one at flush
+    want = [("p", 0)]
+    for f in range(1, n_frames):
+        want += [("p", f), ("c", f - 1)]
+    want.append(("c", n_frames - 1))
+    assert log == want, log
+    if rank == 0:
+        np.save(out_path, np.stack([got[f] for f in range(n_frames)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_key_reduce_pipeline(oracle, tmp_path):
+    """KeyReducePipeline (double-buffered, all-reduce of frame i under the compute of frame
+    i + 1) returns, for every frame, the oracle's WTA over all levels."""
+    w, h, D, F, world = 40, 12, 16, 5, 2
+    costs, want = [], []
+    for f in range(F):
+        left, right = synth.noise_pair(w, h, 1, seed=synth.SEED_NOISE + f)
+        p = oracle.make_params(w, h, 1, disp_max=D - 1, match_fn=1, match_max=3, aggr_window_size=3)
+        c = oracle.aggregate(oracle.raw_costs(left, right, p), p)
+        costs.append(c)
+        want.append(oracle.wta(c))
+    cp, op = str(tmp_path / "costs.npy"), str(tmp_path / "keys.npy")
+    np.save(cp, np.stack(costs))
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), cp, op, F), nprocs=world, join=True)
+    keys = np.load(op)
+    for f in range(F):
+        d, b = sharding.decode_keys(keys[f].T)
+        assert np.array_equal(d, want[f][0])
+        util.assert_bit_equal(b, want[f][1], "frame %d best cost" % f)
