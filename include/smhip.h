@@ -122,6 +122,17 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst,
                          const float *d_cost0, int w, int h, int n_bands,
                          size_t row_elems, float lambda, float beta);
 
+/* n_iter iterations of AggrDiffusion / of the binomial filter (the aggr_iter loop of
+ * StcAggregate.cpp:265-343) with up to four iterations per pass over the DSI (temporal blocking,
+ * csrc/smhip_multi.h); bit-identical to n_iter single calls.  d_a holds the input, d_a and d_b
+ * (distinct, same shape) alternate as source and destination of the passes; *result_in_b says
+ * which one holds the result (hosts swap m_cost / m_cost2 accordingly, StcDiffusion.cpp:58-63). */
+int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_cost0, int w, int h,
+                        int n_bands, size_t row_elems, float lambda, float beta, int n_iter,
+                        int *result_in_b);
+int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int h, int n_bands,
+                             size_t row_elems, int n_iter, int *result_in_b);
+
 /* PadCosts (StcRawCosts.cpp:437-476), any disp_den */
 int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems,
                     const smhip_match_params *p);

@@ -25,6 +25,7 @@ def main():
     re = W * D
     cost, cost2 = ctx.alloc(N * 4), ctx.alloc(N * 4)
     disp, best = ctx.alloc(W * H * 4), ctx.alloc(W * H * 4)
+    disp_src = ctx.alloc(N * 4)          # a third volume: cost0 of the membrane model
     out = {}
 
     def timed(name, nbytes, fn):
@@ -49,6 +50,14 @@ def main():
     timed("convolve_14641_to", 8.0 * N, lambda: ctx.convolve_14641_to(cost, cost2, W, H, D, re))
     timed("diffusion_iter", 8.0 * N, lambda: ctx.diffusion_iter(cost, cost2, None, W, H, D, re, 0.15, 0.0))
     timed("membrane_iter", 12.0 * N, lambda: ctx.diffusion_iter(cost, cost2, cost, W, H, D, re, 0.15, 0.5))
+    for n in (2, 4, 8):
+        timed("binomial x%d (run)" % n, 8.0 * N * n,
+              lambda: ctx.convolve_14641_run(cost, cost2, W, H, D, re, n))
+    for n in (4, 10):
+        timed("diffusion x%d (run)" % n, 8.0 * N * n,
+              lambda: ctx.diffusion_run(cost, cost2, None, W, H, D, re, 0.15, 0.0, n))
+    timed("membrane x4 (run)", 12.0 * N * 4,
+          lambda: ctx.diffusion_run(cost, cost2, disp_src, W, H, D, re, 0.15, 0.5, 4))
     timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
     print(json.dumps({"shape": [W, H, D], "ops": out}))

@@ -22,6 +22,7 @@ SYMBOLS = [
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
+    "smhip_diffusion_run", "smhip_convolve_14641_run",
 ]
 
 
@@ -101,6 +102,8 @@ def load():
     L.smhip_subpixel_fit.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, sz, cf]
     L.smhip_collapse.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, ci, sz, cf, vp, vp]
     L.smhip_refine.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, vp]
+    L.smhip_diffusion_run.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, C.POINTER(ci)]
+    L.smhip_convolve_14641_run.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, C.POINTER(ci)]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
@@ -233,6 +236,19 @@ class Context:
     def diffusion_iter(self, d_src, d_dst, d_cost0, w, h, nb, row_elems, lam, beta):
         self._chk(self.L.smhip_diffusion_iter(self.h, _ptr(d_src), _ptr(d_dst), _ptr(d_cost0),
                                               w, h, nb, row_elems, lam, beta))
+
+    def diffusion_run(self, d_a, d_b, d_cost0, w, h, nb, row_elems, lam, beta, n_iter):
+        """n_iter iterations, up to four per pass; returns True when the result is in d_b."""
+        flag = C.c_int()
+        self._chk(self.L.smhip_diffusion_run(self.h, _ptr(d_a), _ptr(d_b), _ptr(d_cost0), w, h, nb,
+                                             row_elems, lam, beta, n_iter, C.byref(flag)))
+        return bool(flag.value)
+
+    def convolve_14641_run(self, d_a, d_b, w, h, nb, row_elems, n_iter):
+        flag = C.c_int()
+        self._chk(self.L.smhip_convolve_14641_run(self.h, _ptr(d_a), _ptr(d_b), w, h, nb, row_elems,
+                                                  n_iter, C.byref(flag)))
+        return bool(flag.value)
 
     def pad_costs(self, d_cost, row_elems, p):
         self._chk(self.L.smhip_pad_costs(self.h, _ptr(d_cost), row_elems, C.byref(p)))

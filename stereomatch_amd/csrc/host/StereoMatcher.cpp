@@ -203,38 +203,57 @@ void CStereoMatcher::PadCosts()
 
 void CStereoMatcher::Aggregate()
 {
-    for (int iter = 0; iter < aggr_iter; iter++) {
-        switch (aggr_fn) {
-        case eBox:
+    // The aggr_iter loop of StcAggregate.cpp:265-343.  The iterated stencils go to the device as
+    // one call: it runs up to four iterations per pass over the DSI and says which of m_cost /
+    // m_cost2 holds the result.
+    size_t bytes = m_row_elems * m_mp.height * sizeof(float);
+    int in_b = 0;
+    switch (aggr_fn) {
+    case eBox:
+        for (int iter = 0; iter < aggr_iter; iter++) {
             if (verbose >= eVerboseProgress && iter < 3)
                 fprintf(stderr, "- aggregating: box filter, size %d\n", aggr_window_size);
             AggrBox();
-            break;
-        case eBinomial:
-            if (verbose >= eVerboseProgress && iter < 3)
-                fprintf(stderr, "- aggregating: binomial 14641 filter\n");
-            DeviceBuffer(B_COST2, m_row_elems * m_mp.height * sizeof(float));
-            Check(smhip_convolve_14641_to(m_ctx, (const float *)m_dev[B_COST], (float *)m_dev[B_COST2],
-                                          m_mp.width, m_mp.height, m_disp_n, m_row_elems));
-            SwapCost();
-            break;
-        case eDiffusion:
-            if (verbose >= eVerboseProgress && iter < 3)
-                fprintf(stderr, "- aggregating: diffusion, lambda = %g\n", diff_lambda);
-            diff_beta = 0.0f;                                 // StcAggregate.cpp:305
-            AggrDiffusion(iter);
-            break;
-        case eMembrane:
-            if (verbose >= eVerboseProgress && iter < 3)
-                fprintf(stderr, "- aggregating: membrane model, lambda = %g, beta = %g\n", diff_lambda, diff_beta);
-            AggrDiffusion(iter);
-            break;
-        case eBayesian:
-            throw CError("CStereoMatcher::Aggregate(): Bayesian diffusion is not on the device path");
-        default:
-            throw CError("CStereoMatcher::Aggregate(): unknown aggregation function");
         }
+        break;
+    case eBinomial:
+        if (verbose >= eVerboseProgress && aggr_iter > 0)
+            fprintf(stderr, "- aggregating: binomial 14641 filter\n");
+        if (aggr_iter > 0) {
+            DeviceBuffer(B_COST2, bytes);
+            Check(smhip_convolve_14641_run(m_ctx, (float *)m_dev[B_COST], (float *)m_dev[B_COST2], m_mp.width,
+                                           m_mp.height, m_disp_n, m_row_elems, aggr_iter, &in_b));
+        }
+        break;
+    case eDiffusion:
+    case eMembrane:
+        if (aggr_fn == eDiffusion) {
+            if (verbose >= eVerboseProgress && aggr_iter > 0)
+                fprintf(stderr, "- aggregating: diffusion, lambda = %g\n", diff_lambda);
+            if (aggr_iter > 0)
+                diff_beta = 0.0f;                             // StcAggregate.cpp:305
+        } else if (verbose >= eVerboseProgress && aggr_iter > 0) {
+            fprintf(stderr, "- aggregating: membrane model, lambda = %g, beta = %g\n", diff_lambda, diff_beta);
+        }
+        if (aggr_iter > 0) {
+            if (diff_beta > 0.0f)                             // StcDiffusion.cpp:52-56
+                Check(smhip_memcpy_d2d(m_ctx, DeviceBuffer(B_COST0, bytes), m_dev[B_COST], bytes));
+            DeviceBuffer(B_COST2, bytes);
+            Check(smhip_diffusion_run(m_ctx, (float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                                      diff_beta > 0.0f ? (const float *)m_dev[B_COST0] : nullptr, m_mp.width,
+                                      m_mp.height, m_disp_n, m_row_elems, diff_lambda, diff_beta, aggr_iter,
+                                      &in_b));
+        }
+        break;
+    case eBayesian:
+        throw CError("CStereoMatcher::Aggregate(): Bayesian diffusion is not on the device path");
+    default:
+        throw CError("CStereoMatcher::Aggregate(): unknown aggregation function");
     }
+    if (in_b)
+        SwapCost();
+    if (verbose >= eVerboseProgress && aggr_iter > 3)
+        fprintf(stderr, "...  (doing %d iterations total)\n", aggr_iter);
     if (aggr_minfilter > 1) {
         if (verbose >= eVerboseProgress)
             fprintf(stderr, "- min filter (shiftable windows): filter size %d\n", aggr_minfilter);

@@ -7,6 +7,7 @@
 #include "smhip_subpix.h"
 #include "smhip_stage.h"
 #include "smhip_refine.h"
+#include "smhip_multi.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -600,6 +601,113 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst, const
     if (vec == 4) { if (mem) LAUNCH_DIFF(4, true); else LAUNCH_DIFF(4, false); }
     else          { if (mem) LAUNCH_DIFF(1, true); else LAUNCH_DIFF(1, false); }
 #undef LAUNCH_DIFF
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+// iterations per pass for n_iter iterations: ceil(n/4) passes of nearly equal depth
+static int multi_depth(int remaining, int passes_left)
+{
+    return (remaining + passes_left - 1) / passes_left;
+}
+
+int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_cost0, int w, int h,
+                        int nb, size_t row_elems, float lambda, float beta, int n_iter, int *result_in_b)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_a, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_b || d_b == d_a || !result_in_b)
+        return fail(SMHIP_EINVAL, "diffusion needs two distinct buffers and a result flag");
+    if (n_iter < 0)
+        return fail(SMHIP_EINVAL, "negative iteration count");
+    if (beta > 0.0f && !d_cost0)
+        return fail(SMHIP_EINVAL, "membrane model (beta > 0) needs the initial DSI");
+    const bool mem = beta > 0.0f;
+    float *cur = d_a, *oth = d_b;
+    *result_in_b = 0;
+    const int tseg = h >= 1024 ? 128 : 64;
+    const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
+    if (walk_vec(nb, row_elems, d_a, d_b, mem ? d_cost0 : nullptr) != 4 || gy > 65535 || gz > 65535) {
+        for (int i = 0; i < n_iter; i++) {          // unaligned shapes: one iteration per pass
+            rc = smhip_diffusion_iter(ctx, cur, oth, d_cost0, w, h, nb, row_elems, lambda, beta);
+            if (rc) return rc;
+            float *t = cur; cur = oth; oth = t;
+            *result_in_b ^= 1;
+        }
+        return SMHIP_OK;
+    }
+    float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
+    float lb = lambda * beta;            // :132
+    int passes = (n_iter + 3) / 4;
+    for (int left = n_iter; left > 0; passes--) {
+        int K = multi_depth(left, passes);
+        dim3 grid((w + (smk::MULTI_TXT - 2 * K) - 1) / (smk::MULTI_TXT - 2 * K), gy, gz);
+#define LAUNCH_DM(KK)                                                                              \
+        do {                                                                                       \
+            if (mem) smk::diffusion_multi_kernel<KK, true><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(  \
+                cur, oth, d_cost0, w, nb, h, row_elems, tseg, lambda, a, lb);                      \
+            else smk::diffusion_multi_kernel<KK, false><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(     \
+                cur, oth, d_cost0, w, nb, h, row_elems, tseg, lambda, a, lb);                      \
+        } while (0)
+        switch (K) {
+        case 1: LAUNCH_DM(1); break;
+        case 2: LAUNCH_DM(2); break;
+        case 3: LAUNCH_DM(3); break;
+        default: LAUNCH_DM(4); break;
+        }
+#undef LAUNCH_DM
+        left -= K;
+        float *t = cur; cur = oth; oth = t;
+        *result_in_b ^= 1;
+    }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int h, int nb,
+                             size_t row_elems, int n_iter, int *result_in_b)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_a, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_b || d_b == d_a || !result_in_b)
+        return fail(SMHIP_EINVAL, "ConvolveSeparable: needs two distinct buffers and a result flag");
+    if (n_iter < 0)
+        return fail(SMHIP_EINVAL, "negative iteration count");
+    float *cur = d_a, *oth = d_b;
+    *result_in_b = 0;
+    const int tseg = h >= 1024 ? 128 : 64;
+    const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
+    if (walk_vec(nb, row_elems, d_a, d_b, nullptr) != 4 || gy > 65535 || gz > 65535) {
+        for (int i = 0; i < n_iter; i++) {
+            rc = smhip_convolve_14641_to(ctx, cur, oth, w, h, nb, row_elems);
+            if (rc) return rc;
+            float *t = cur; cur = oth; oth = t;
+            *result_in_b ^= 1;
+        }
+        return SMHIP_OK;
+    }
+    int passes = (n_iter + 3) / 4;
+    for (int left = n_iter; left > 0; passes--) {
+        int K = multi_depth(left, passes);
+        if (K == 1) {                               // the one-iteration tile kernel has the smaller halo
+            rc = smhip_convolve_14641_to(ctx, cur, oth, w, h, nb, row_elems);
+            if (rc) return rc;
+        } else {
+            dim3 grid((w + (smk::MULTI_TXT - 4 * K) - 1) / (smk::MULTI_TXT - 4 * K), gy, gz);
+            switch (K) {
+            case 2: smk::binomial_multi_kernel<2><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            case 3: smk::binomial_multi_kernel<3><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            default: smk::binomial_multi_kernel<4><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            }
+        }
+        left -= K;
+        float *t = cur; cur = oth; oth = t;
+        *result_in_b ^= 1;
+    }
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

@@ -151,21 +151,25 @@ class StereoMatcher(StereoParameters):
         if self.aggr_fn == eMembrane and beta > 0.0 and self.aggr_iter > 0:
             cost0 = self._buf("cost0", nbytes)                          # :262
             self._copy(cost0, self.d_cost, nbytes)
-        for _ in range(self.aggr_iter):
-            if self.aggr_fn == eBox:
+        # the aggr_iter loop (StcAggregate.cpp:265-343); the iterated stencils run up to four
+        # iterations per pass over the DSI (smhip_*_run), with the reference's ping-pong of
+        # m_cost / m_cost2 (StcDiffusion.cpp:58-63)
+        if self.aggr_fn == eBox:
+            for _ in range(self.aggr_iter):
                 c.box_filter(self.d_cost, w, h, nb, re, self.aggr_window_size)
-            elif self.aggr_fn == eBinomial:
-                other = self._buf("cost2", nbytes)      # ConvolveSeparable(src, dst, ...): ping-pong
-                c.convolve_14641_to(self.d_cost, other, w, h, nb, re)
-                self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
-                self.d_cost = other
-            elif self.aggr_fn in (eDiffusion, eMembrane):
-                other = self._buf("cost2", nbytes)                      # StcDiffusion.cpp:58-63
-                c.diffusion_iter(self.d_cost, other, cost0, w, h, nb, re, self.diff_lambda, beta)
-                self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
-                self.d_cost = other
-            else:
-                raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
+        elif self.aggr_fn in (eBinomial, eDiffusion, eMembrane):
+            if self.aggr_iter > 0:
+                other = self._buf("cost2", nbytes)
+                if self.aggr_fn == eBinomial:
+                    in_b = c.convolve_14641_run(self.d_cost, other, w, h, nb, re, self.aggr_iter)
+                else:
+                    in_b = c.diffusion_run(self.d_cost, other, cost0, w, h, nb, re, self.diff_lambda,
+                                           beta, self.aggr_iter)
+                if in_b:
+                    self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+                    self.d_cost = other
+        else:
+            raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
         if self.aggr_minfilter > 1:                                      # :351-360
             other = self._buf("cost2", nbytes)
             c.min_filter_to(self.d_cost, other, w, h, nb, re, self.aggr_minfilter)

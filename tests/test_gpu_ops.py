@@ -289,3 +289,35 @@ def test_subpixel_fit_collapse_refine(gpu_ctx, oracle, h, w, d):
                                   oracle.refine(wc, wm, disp, step, dmn, mode), "refine %d" % mode)
     with pytest.raises(capi.SmhipError):
         gpu_ctx.collapse(dst, dmin, w, h, d, w * d, 2, d, w * d, 0.5, dst, dmin)
+
+
+@pytest.mark.parametrize("h,w,d,pad", [(9, 21, 8, 0), (150, 70, 12, 0), (70, 150, 40, 4), (3, 5, 4, 0),
+                                       (40, 130, 7, 1)])
+@pytest.mark.parametrize("n_iter", [1, 2, 3, 4, 5, 7, 10])
+def test_multi_iteration_passes(gpu_ctx, oracle, h, w, d, pad, n_iter):
+    """smhip_diffusion_run / smhip_convolve_14641_run: up to four iterations per pass (temporal
+    blocking across tiles of 64 pixels and row segments) == n_iter single iterations of the
+    oracle, bit for bit; unaligned shapes take the one-iteration-per-pass route."""
+    c = util.rand_dsi(h, w, d, 80 + n_iter, "float")
+    c0 = util.rand_dsi(h, w, d, 81, "float")
+    re = w * d + pad
+    def padded(a):
+        out = np.zeros((h, re), np.float32)
+        out[:, :w * d] = a.reshape(h, w * d)
+        return out
+    def result(bufs, in_b):
+        return gpu_ctx.download(bufs[1] if in_b else bufs[0], (h, re), np.float32)[:, :w * d].reshape(h, w, d)
+    b0 = up(gpu_ctx, padded(c0))
+    for beta in (0.0, 0.5):
+        want = c
+        for _ in range(n_iter):
+            want = oracle.diffusion_iter(want, 0.15, beta, c0)
+        bufs = (up(gpu_ctx, padded(c)), gpu_ctx.alloc(h * re * 4))
+        in_b = gpu_ctx.diffusion_run(bufs[0], bufs[1], b0 if beta > 0 else None, w, h, d, re, 0.15, beta, n_iter)
+        util.assert_bit_equal(result(bufs, in_b), want, "diffusion x%d beta %g" % (n_iter, beta))
+    want = c
+    for _ in range(n_iter):
+        want = oracle.convolve_14641(want)
+    bufs = (up(gpu_ctx, padded(c)), gpu_ctx.alloc(h * re * 4))
+    in_b = gpu_ctx.convolve_14641_run(bufs[0], bufs[1], w, h, d, re, n_iter)
+    util.assert_bit_equal(result(bufs, in_b), want, "binomial x%d" % n_iter)
