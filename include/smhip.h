@@ -178,6 +178,23 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
 int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                              size_t img_pitch, const smhip_match_params *p, int window,
                              int d_first, int d_count, int64_t *d_keys);
+/* The first half of the above with the aggregated DSI as the result: RawCosts + one AggrBox of
+ * levels [d_first, d_first + d_count) written to d_cost[h][row_elems] (d_count levels per pixel,
+ * NOT yet padded: AggrMin / PadCosts / ... follow as in StcAggregate.cpp:351-400).  12 bytes per
+ * voxel of HBM traffic instead of the 20 of smhip_raw_costs + smhip_box_filter.  Needs
+ * d_count >= 33, d_count % 4 == 0, row_elems % 4 == 0, 16-byte aligned d_cost and disp_den == 1
+ * (SMHIP_EINVAL otherwise: use the stage calls). */
+int smhip_fused_box_dsi(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                        size_t img_pitch, const smhip_match_params *p, int window,
+                        int d_first, int d_count, float *d_cost, size_t row_elems);
+/* AggrMin (window x window, odd, 3..11) + PadCosts + OptWTA on a resident DSI of d_count levels
+ * (global levels d_first ...) without writing the filtered DSI: one read of d_cost, keys out
+ * (same format as smhip_fused_box_wta_keys).  The exp2 pipeline (Scripts/exp2_costSSDMF9.txt) is
+ * smhip_fused_box_dsi + this call: 16 bytes per voxel.  Needs d_count % 4 == 0, row_elems % 4 == 0,
+ * 16-byte aligned d_cost. */
+int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems,
+                           const smhip_match_params *p, int min_window, int d_first, int d_count,
+                           int64_t *d_keys);
 /* column-major keys -> row-major disparity and best cost images (either may be NULL) */
 int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int height,
                       int32_t *d_disp, float *d_best);

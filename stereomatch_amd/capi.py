@@ -23,6 +23,7 @@ SYMBOLS = [
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
+    "smhip_fused_box_dsi", "smhip_min_pad_wta_keys",
 ]
 
 
@@ -104,6 +105,8 @@ def load():
     L.smhip_refine.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, vp]
     L.smhip_diffusion_run.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, C.POINTER(ci)]
     L.smhip_convolve_14641_run.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, C.POINTER(ci)]
+    L.smhip_fused_box_dsi.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp, sz]
+    L.smhip_min_pad_wta_keys.argtypes = [vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
@@ -261,6 +264,14 @@ class Context:
         self._chk(self.L.smhip_fused_box_wta_keys(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
                                                   C.byref(p), window, d_first, d_count,
                                                   _ptr(d_keys)))
+
+    def fused_box_dsi(self, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_cost, row_elems):
+        self._chk(self.L.smhip_fused_box_dsi(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch, C.byref(p),
+                                             window, d_first, d_count, _ptr(d_cost), row_elems))
+
+    def min_pad_wta_keys(self, d_cost, row_elems, p, min_window, d_first, d_count, d_keys):
+        self._chk(self.L.smhip_min_pad_wta_keys(self.h, _ptr(d_cost), row_elems, C.byref(p), min_window,
+                                                d_first, d_count, _ptr(d_keys)))
 
     def keys_decode(self, d_keys, width, height, d_disp, d_best):
         """d_keys: width*height int64, column-major (pixel (x, y) at x*height + y)."""

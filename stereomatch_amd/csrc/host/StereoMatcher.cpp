@@ -48,6 +48,22 @@ bool CStereoMatcher::Fusable() const
            m_disp_den == 1 && verbose < eVerboseDumpFiles;
 }
 
+bool CStereoMatcher::BoxDsiFusable() const
+{
+    // RawCosts + one AggrBox in two passes over a private slab (12 instead of 20 bytes per voxel)
+    return allow_fused && aggr_fn == eBox && aggr_iter == 1 && m_disp_den == 1 && m_disp_n >= 33 &&
+           m_disp_n % 4 == 0 && (m_mp.n_bands == 1 || m_reference.RowBytes() % 4 == 0) &&
+           !eval_match_quality && verbose < eVerboseDumpFiles;
+}
+
+bool CStereoMatcher::MinWtaFusable() const
+{
+    // AggrMin + PadCosts + OptWTA without writing the filtered DSI
+    return allow_fused && aggr_minfilter >= 3 && aggr_minfilter <= 11 && aggr_minfilter % 2 == 1 &&
+           opt_fn == eWTA && m_disp_den == 1 && m_disp_n % 4 == 0 && !refine_subpix && !aggr_subpixel &&
+           !aggr_collapse && !eval_match_quality && verbose < eVerboseDumpFiles;
+}
+
 void CStereoMatcher::ComputeCorrespondence()
 {
     if (frame_ref < 0 || frame_ref >= (int)m_frame.size())
@@ -116,6 +132,7 @@ void CStereoMatcher::ComputeCorrespondence()
     DeviceBuffer(B_BEST, n_pix * sizeof(float));
 
     PreProcess();
+    m_keys_done = m_raw_deferred = false;
     m_used_fused = Fusable();
     if (m_used_fused) {
         if (verbose >= eVerboseProgress)
@@ -160,12 +177,22 @@ void CStereoMatcher::RawCosts()
                 match_max < 1000 ? ", trunc" : "", match_interval ? ", interval" : "");
     m_row_elems = (size_t)m_mp.width * m_disp_n;
     DeviceBuffer(B_COST, m_row_elems * m_mp.height * sizeof(float));
+    m_keys_done = false;
+    m_raw_deferred = BoxDsiFusable();
+    if (m_raw_deferred)
+        return;                                               // made inside AggrBox
     Check(smhip_raw_costs(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
                           m_reference.RowBytes(), &m_mp, (float *)m_dev[B_COST], m_row_elems));
 }
 
 void CStereoMatcher::AggrBox()
 {
+    if (m_raw_deferred) {
+        Check(smhip_fused_box_dsi(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
+                                  m_reference.RowBytes(), &m_mp, aggr_window_size, 0, m_disp_n,
+                                  (float *)m_dev[B_COST], m_row_elems));
+        return;
+    }
     Check(smhip_box_filter(m_ctx, (float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
                            aggr_window_size, aggr_window_size, 1));
 }
@@ -257,6 +284,17 @@ void CStereoMatcher::Aggregate()
     if (aggr_minfilter > 1) {
         if (verbose >= eVerboseProgress)
             fprintf(stderr, "- min filter (shiftable windows): filter size %d\n", aggr_minfilter);
+        if (MinWtaFusable()) {                                // + PadCosts + OptWTA, keys out
+            size_t n_pix = (size_t)m_mp.width * m_mp.height;
+            DeviceBuffer(B_KEYS, n_pix * sizeof(int64_t));
+            Check(smhip_min_pad_wta_keys(m_ctx, (const float *)m_dev[B_COST], m_row_elems, &m_mp, aggr_minfilter,
+                                         0, m_disp_n, (int64_t *)m_dev[B_KEYS]));
+            Check(smhip_keys_decode(m_ctx, (const int64_t *)m_dev[B_KEYS], m_mp.width, m_mp.height,
+                                    (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
+            m_keys_done = true;
+            m_have_mind = false;
+            return;
+        }
         AggrMin();
     }
     PadCosts();
@@ -323,7 +361,7 @@ void CStereoMatcher::Optimize()
         throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) is on the device path");
     if (verbose >= eVerboseProgress)
         fprintf(stderr, "- optimizing: WTA (local minimum)\n");
-    if (!m_used_fused)
+    if (!m_used_fused && !m_keys_done)
         OptWTA();
     // results to the host (disparity rows are 4*W bytes: already a multiple of 8 or padded here)
     size_t wbytes = (size_t)m_mp.width * 4;

@@ -47,13 +47,17 @@ protected:
     float m_disp_step, m_disp_step_inv, m_match_outside;
     int m_disp_n, m_disp_num, m_disp_den, m_frame_diff, m_frame_diff_sign;
     bool m_used_fused = false;
+    bool m_raw_deferred = false;        // RawCosts + AggrBox run as one smhip_fused_box_dsi call
+    bool m_keys_done = false;           // AggrMin + PadCosts + OptWTA already ran as smhip_min_pad_wta_keys
+    bool BoxDsiFusable() const;
+    bool MinWtaFusable() const;
     bool m_have_mind = false;           // m_sub_pixel_min holds offsets (StcAggregate.cpp:77,228)
     CByteImage m_reference, m_matching;
     CIntImage m_disparity;              // winning levels [0 .. m_disp_n-1]
     CFloatImage m_best_cost;            // m_cost at the winner (data term of final_energy)
     CFloatImage m_float_disparity;
     size_t m_row_elems = 0;
-    enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_MIND, B_CERT, B_FDISP, B_COUNT };
+    enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_MIND, B_CERT, B_FDISP, B_KEYS, B_COUNT };
     void *m_dev[B_COUNT];
     size_t m_dev_bytes[B_COUNT];
     std::vector<CStereoFrame> m_frame;

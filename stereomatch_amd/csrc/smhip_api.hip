@@ -860,10 +860,13 @@ int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int heig
     return SMHIP_OK;
 }
 
-int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
-                             size_t img_pitch, const smhip_match_params *p, int window,
-                             int d_first, int d_count, int64_t *d_keys)
+// RawCosts + one AggrBox on the slab [d_first, d_first + d_count), then either PadCosts + WTA ->
+// keys (d_keys) or the aggregated DSI itself (d_dsi, reference layout, no PadCosts yet).
+static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                      const smhip_match_params *p, int window, int d_first, int d_count,
+                      int64_t *d_keys, float *d_dsi, size_t dsi_row_elems)
 {
+    const int keep_all = d_dsi != nullptr;
     int rc = check_ctx(ctx);
     if (rc) return rc;
     rc = check_params(p, d_ref, d_mtc, img_pitch);
@@ -871,8 +874,8 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     if (p->disp_den != 1)   // the hosts route disp_step < 1 through the staged entry points
         return fail(SMHIP_EINVAL, "fused path: disp_step < 1 (den=%d) not supported, use smhip_raw_costs",
                     p->disp_den);
-    if (!d_keys)
-        return fail(SMHIP_EINVAL, "null key buffer");
+    if (!d_keys && !d_dsi)
+        return fail(SMHIP_EINVAL, "null output buffer");
     if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
         return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count,
                     p->disp_n);
@@ -902,6 +905,9 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     const bool wide = (Dp % 64 == 0);
     const bool tuned_a = wide && (p->n_bands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
                                                       ((uintptr_t)d_mtc & 3) == 0));
+    if (keep_all && !(wide && tuned_a && d_count % 4 == 0 && dsi_row_elems % 4 == 0 &&
+                      ((uintptr_t)d_dsi & 15) == 0))
+        return fail(SMHIP_EINVAL, "fused box -> DSI needs >= 33 levels, D %% 4 == 0 and 16-byte aligned rows");
     // banded slab layout (smhip_fused.h) only when both passes are the tuned kernels
     int tyshift = tuned_a ? 5 : 0;
     if (const char *e = getenv("SMHIP_TYSHIFT")) { if (tuned_a) tyshift = atoi(e); }
@@ -918,7 +924,7 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     rc = ws_get(ctx, WS_TMP, t_elems * sizeof(float), &T);
     if (rc) return rc;
     long long *kout = (long long *)d_keys;
-    if (n_chunks > 1) {
+    if (n_chunks > 1 && !keep_all) {
         void *part = nullptr;
         rc = ws_get(ctx, WS_KEYS, n_pix * n_chunks * sizeof(long long), &part);
         if (rc) return rc;
@@ -943,7 +949,7 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
 #define LAUNCH_A3(WIN, SD, NB) smk::fused_rawbox_h_lds_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>( \
-        fa, (float *)T, tyshift, Dp, window, scale)
+        fa, (float *)T, tyshift, Dp, window, scale, keep_all)
 #define LAUNCH_A(WIN)                                                             \
         do {                                                                      \
             if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
@@ -973,7 +979,7 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         // one wave per pixel column and chunk, 4 columns per block, columns dealt per XCD
         const int wpb = 4;
         int x_per_xcd = (W + 7) / 8;
-        dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), n_chunks);
+        dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), keep_all ? (Dp + 255) / 256 : n_chunks);
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, 0, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
         d_first, x_per_xcd, kout, n_pix)
@@ -983,13 +989,28 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         case 2: LAUNCH_BT(WIN, 2); break;              \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
-        switch (window) {            // static windows: the leaving row comes from registers
-        case 3: LAUNCH_BW(3) break;
-        case 5: LAUNCH_BW(5) break;
-        case 7: LAUNCH_BW(7) break;
-        case 9: LAUNCH_BW(9) break;
-        case 11: LAUNCH_BW(11) break;
-        default: LAUNCH_BW(0) break;
+        if (!keep_all) {
+            switch (window) {        // static windows: the leaving row comes from registers
+            case 3: LAUNCH_BW(3) break;
+            case 5: LAUNCH_BW(5) break;
+            case 7: LAUNCH_BW(7) break;
+            case 9: LAUNCH_BW(9) break;
+            case 11: LAUNCH_BW(11) break;
+            default: LAUNCH_BW(0) break;
+            }
+        } else {                     // aggregated DSI out: 4 levels per lane, d_count % 4 == 0
+#define LAUNCH_BS(WIN) smk::fused_boxv_wta_vpl_kernel<WIN, 4, 0, true><<<gb, 64 * wpb, 0, ctx->stream>>>( \
+        (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,           \
+        d_first, x_per_xcd, nullptr, 0, d_dsi, dsi_row_elems)
+            switch (window) {
+            case 3: LAUNCH_BS(3); break;
+            case 5: LAUNCH_BS(5); break;
+            case 7: LAUNCH_BS(7); break;
+            case 9: LAUNCH_BS(9); break;
+            case 11: LAUNCH_BS(11); break;
+            default: LAUNCH_BS(0); break;
+            }
+#undef LAUNCH_BS
         }
 #undef LAUNCH_BW
 #undef LAUNCH_BT
@@ -1008,13 +1029,76 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
         }
 #undef LAUNCH_B
     }
-    if (n_chunks > 1)
+    if (n_chunks > 1 && !keep_all)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
             kout, n_chunks, n_pix, (long long *)d_keys);
     if (prof) {
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
         ctx->ev_used++;
     }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                             size_t img_pitch, const smhip_match_params *p, int window,
+                             int d_first, int d_count, int64_t *d_keys)
+{
+    if (!d_keys)
+        return fail(SMHIP_EINVAL, "null key buffer");
+    return fused_impl(ctx, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_keys, nullptr, 0);
+}
+
+int smhip_fused_box_dsi(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                        const smhip_match_params *p, int window, int d_first, int d_count,
+                        float *d_cost, size_t row_elems)
+{
+    if (!p)
+        return fail(SMHIP_EINVAL, "null argument");
+    int rc = check_dsi(d_cost, p->width, p->height, d_count > 0 ? d_count : 1, row_elems);
+    if (rc) return rc;
+    return fused_impl(ctx, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, nullptr, d_cost, row_elems);
+}
+
+int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems,
+                           const smhip_match_params *p, int min_window, int d_first, int d_count,
+                           int64_t *d_keys)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!p || !d_keys)
+        return fail(SMHIP_EINVAL, "null argument");
+    if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
+        return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count, p->disp_n);
+    if (p->disp_den != 1)
+        return fail(SMHIP_EINVAL, "min filter + WTA keys: disp_step < 1 not supported, use the stage calls");
+    int w = p->width, h = p->height;
+    rc = check_dsi(d_cost, w, h, d_count, row_elems);
+    if (rc) return rc;
+    const int tseg = h >= 1024 ? 128 : 64;
+    dim3 tgrid((w + 31) / 32, (d_count + 31) / 32, (h + tseg - 1) / tseg);
+    if (walk_vec(d_count, row_elems, d_cost, nullptr, nullptr) != 4 || min_window % 2 != 1 || min_window < 3 ||
+        min_window > 11 || tgrid.y > 65535 || tgrid.z > 65535)
+        return fail(SMHIP_EINVAL, "min filter + WTA keys needs an odd window 3..11, D %% 4 == 0 and 16-byte aligned rows");
+    size_t n_pix = (size_t)w * h;
+    smk::fill_keys_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        (long long *)d_keys, n_pix, 0x7FFFFFFFFFFFFFFFll);
+    smk::PadWtaArgs pw;
+    pw.dstep = -p->frame_diff_sign * p->disp_num;
+    pw.disp0 = -p->frame_diff_sign * p->disp_min + d_first * pw.dstep;
+    pw.d_first = d_first;
+    pw.outside = smhip_match_outside(p);
+    pw.keys = (long long *)d_keys;
+#define LAUNCH_TW(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32, true><<<tgrid, 256, 0, ctx->stream>>>( \
+        d_cost, nullptr, w, d_count, h, row_elems, tseg, pw)
+    switch (min_window) {
+    case 3: LAUNCH_TW(3); break;
+    case 5: LAUNCH_TW(5); break;
+    case 7: LAUNCH_TW(7); break;
+    case 9: LAUNCH_TW(9); break;
+    default: LAUNCH_TW(11); break;
+    }
+#undef LAUNCH_TW
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

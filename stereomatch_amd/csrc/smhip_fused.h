@@ -8,6 +8,8 @@
 //   the window from a register ring (window size is a template parameter, so ring slots are
 //   static).  Each step a wave stores 64 consecutive floats (256 B) of the slab T.
 //   HBM traffic: W*H*Dp*4 bytes written, images read once.
+//   keep_all = 0: elements that PadCosts will overwrite right after the box filter are not
+//   stored (pass B skips them too); keep_all = 1 (a min filter follows): everything is stored.
 #pragma once
 
 #include "smhip_kernels.h"
@@ -82,7 +84,7 @@ template <> struct RowLds<4> {
 template <int WIN, bool SD, int NB>
 __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float *__restrict__ T,
                                                                  int tyshift, int Dp, int win,
-                                                                 float scale)
+                                                                 float scale, int keep_all)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_a[];
     const int W = a.W;
@@ -148,7 +150,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
                     int c = cost(min(x + pr, W - 1));
                     acc = acc + scale * (float)(c - ring[s]);
                     ring[s] = c;
-                    if ((unsigned)(x + disp) < (unsigned)W)   // PadCosts overwrites the rest: never read
+                    if (keep_all || (unsigned)(x + disp) < (unsigned)W)   // PadCosts overwrites the rest: never read
                         t[xs * x] = acc;
                 }
             }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
                 int c = cost(min(x + pr, W - 1));
                 acc = acc + scale * (float)(c - ring[s]);
                 ring[s] = c;
-                if ((unsigned)(x + disp) < (unsigned)W)
+                if (keep_all || (unsigned)(x + disp) < (unsigned)W)
                     t[xs * x] = acc;
             }
         }
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float
             int cl = cost(max(x + pl, 0));
             int cr = cost(min(x + pr, W - 1));
             acc = acc + scale * (float)(cr - cl);
-            if ((unsigned)(x + disp) < (unsigned)W)
+            if (keep_all || (unsigned)(x + disp) < (unsigned)W)
                 t[xs * x] = acc;
         }
     }

@@ -38,11 +38,16 @@ __device__ __forceinline__ void load_row(const float *p, float (&v)[VPL])
 // WIN > 0: static window, blocks of WIN rows, the row leaving the window is the row that
 // entered one block earlier (registers).  WIN == 0: generic window, blocks of 8 rows, the
 // leaving row is re-read.  blockDim.x = 64 * (pixel columns per block), one wave per column.
-template <int WIN, int VPL, int ABL = 0>   // ABL: ablation switches of scripts/bench_b.hip (0 = product)
+// STORE = true: the same walk, but instead of PadCosts + WTA every aggregated row is written to
+// the DSI S[y][x][D] (reference layout, row stride s_row_elems; D % VPL == 0): RawCosts + one
+// AggrBox with 12 bytes per voxel instead of 20.  All levels are kept (the min filter that may
+// follow reads the aggregated costs of padded positions too, StcAggregate.cpp:351-365).
+template <int WIN, int VPL, int ABL = 0, bool STORE = false>   // ABL: ablation switches of scripts/bench_b.hip (0 = product)
 __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
-    long long *__restrict__ keys, size_t keys_chunk_stride)
+    long long *__restrict__ keys, size_t keys_chunk_stride, float *__restrict__ S = nullptr,
+    size_t s_row_elems = 0)
 {
     constexpr int BLK = WIN ? WIN : 8;
     constexpr int GRP = (64 / BLK) * BLK;              // rows per key store (63 for WIN 9)
@@ -78,7 +83,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     bool need = false;
 #pragma unroll
     for (int i = 0; i < VPL; i++)
-        need = need || (live[i] && !padded[i]);
+        need = need || (live[i] && (STORE || !padded[i]));
+    float *sout = STORE ? S + (size_t)x * D + (k0 < D ? k0 : 0) : nullptr;
     auto ld = [&](int row, float(&v)[VPL]) {
         if (need)
             load_row<VPL>(T + slab_row_offset(clampi(row, H), W, Dp, tyshift) + j, v);
@@ -103,7 +109,18 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
 
     int key_lo = 0, key_hi = 0;
     // slot = lane that keeps the key of this row
-    auto step = [&](const float(&od)[VPL], const float(&nw)[VPL], int slot) {
+    auto step = [&](const float(&od)[VPL], const float(&nw)[VPL], int slot, int y) {
+        if constexpr (STORE) {
+            typename vecf<VPL>::type o;
+#pragma unroll
+            for (int i = 0; i < VPL; i++) {
+                acc[i] = acc[i] + scale * (-od[i] + nw[i]);
+                if constexpr (VPL == 1) o = acc[0]; else o[i] = acc[i];
+            }
+            if (need && y < H)
+                *(typename vecf<VPL>::type *)(sout + (size_t)y * s_row_elems) = o;
+            return;
+        }
         float best = 0;
         int bi = 0;
 #pragma unroll
@@ -133,6 +150,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     };
     // after the block that starts at row yb: store the group's keys when it is complete
     auto flush = [&](int yb) {
+        if constexpr (STORE)
+            return;
         int g0 = (yb / GRP) * GRP;                      // first row of the group
         bool last = yb + BLK >= H;
         if (yb + BLK - g0 == GRP || last) {
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
 #pragma unroll
             for (int r = 0; r < BLK; r++) {
                 ld(yb + BLK + r + pr, nxt[r]);          // rolling prefetch, one block ahead
-                step(prv[r], cur[r], slot0 + r);
+                step(prv[r], cur[r], slot0 + r, yb + r);
             }
             flush(yb);
         };
@@ -192,7 +211,7 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                     for (int r = 0; r < BLK; r++) {
                         ld(yb + BLK + r + pr, nw[half ^ 1][r]);
                         ld(yb + BLK + r + pl, od[half ^ 1][r]);
-                        step(od[half][r], nw[half][r], slot0 + r);
+                        step(od[half][r], nw[half][r], slot0 + r, yb + r);
                     }
                     flush(yb);
                 }

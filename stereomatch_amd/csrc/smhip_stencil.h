@@ -179,6 +179,7 @@ __global__ __launch_bounds__(256) void minfilter_walk_kernel(const float *__rest
 // HBM traffic: (1 + (WIN-1)/TX) reads + 1 write per voxel.
 template <int WIN_> struct MinOp {
     static constexpr int WIN = WIN_;
+    static constexpr bool SYMMETRIC = true;     // v() does not depend on the order of the rows
     typedef typename fvec<4>::type vec;
     static __device__ __forceinline__ vec h(const vec *w)
     {
@@ -192,15 +193,47 @@ template <int WIN_> struct MinOp {
 };
 struct BinomOp {
     static constexpr int WIN = 5;
+    static constexpr bool SYMMETRIC = false;
     typedef typename fvec<4>::type vec;
     static __device__ __forceinline__ vec h(const vec *w) { return vtap5<4>(w[0], w[1], w[2], w[3], w[4]); }
     static __device__ __forceinline__ vec v(const vec *r) { return vtap5<4>(r[0], r[1], r[2], r[3], r[4]); }
 };
 
-template <class OP, int TX>
+// WTA = true: the filtered value is not stored; PadCosts (StcRawCosts.cpp:437-457) is applied in
+// registers, the 8 lanes of a pixel min-reduce (ordered cost, level) and one lane merges the
+// result of this 32-level tile into the pixel's key with a 64-bit atomic min (keys start at
+// INT64_MAX; column-major like the fused path).  The filtered DSI is never written.
+// Lexicographic (s, d) minimum of each aligned group of 8 lanes, delivered to the group's first
+// lane (DPP row_shl 1, 2, 4; the levels of a group ascend with the lane, so on equal s the lower
+// lane keeps its own pair).
+__device__ __forceinline__ void seg8_min_to_first(int &s, int &d)
+{
+#define SMK_SEG8_STEP(CTRL)                                                              \
+    {                                                                                    \
+        int os = __builtin_amdgcn_update_dpp(0x7FFFFFFF, s, CTRL, 0xF, 0xF, false);      \
+        int od = __builtin_amdgcn_update_dpp(0x7FFFFFFF, d, CTRL, 0xF, 0xF, false);      \
+        bool take = os < s;                                                              \
+        s = take ? os : s;                                                               \
+        d = take ? od : d;                                                               \
+    }
+    SMK_SEG8_STEP(0x101)   // row_shl:1
+    SMK_SEG8_STEP(0x102)   // row_shl:2
+    SMK_SEG8_STEP(0x104)   // row_shl:4
+#undef SMK_SEG8_STEP
+}
+
+struct PadWtaArgs {
+    int disp0, dstep;        // disp(k) = disp0 + k*dstep for level k of this DSI
+    int d_first;             // global index of level 0
+    float outside;
+    long long *keys;
+};
+
+template <class OP, int TX, bool WTA = false>
 __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restrict__ src,
                                                            float *__restrict__ dst, int W, int D, int H,
-                                                           size_t row_elems, int seglen)
+                                                           size_t row_elems, int seglen,
+                                                           PadWtaArgs pw = PadWtaArgs())
 {
     typedef typename fvec<4>::type vec;
     constexpr int WIN = OP::WIN, PR = WIN / 2, PL = PR - WIN;
@@ -235,32 +268,82 @@ __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restri
 #pragma unroll
     for (int j = 0; j < WIN; j++)
         ring[j] = 0.0f;
+    // PadCosts flags of this thread's four levels (they do not depend on the row)
+    bool padded[4] = {false, false, false, false};
+    if constexpr (WTA) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int xm = x0 + px + pw.disp0 + (k0 + lq * 4 + e) * pw.dstep;
+            padded[e] = (unsigned)xm >= (unsigned)W;
+        }
+    }
     int buf = 0;
     const int ylast = y1 - 1 + PR;
     gload(y0 + PL + 1);
-    for (int yy = y0 + PL + 1; yy <= ylast; yy++) {
+    // Rows are taken in groups of WIN so that a symmetric operator can overwrite the oldest ring
+    // slot in place (static slot index) instead of shifting the ring.
+    for (int yb = y0 + PL + 1; yb <= ylast; yb += WIN) {
 #pragma unroll
-        for (int n = 0; n < NL; n++)
-            if (t + n * NT < HX * 8)
-                lds[buf][t + n * NT] = g[n];
-        if (yy < ylast)
-            gload(yy + 1);
-        __syncthreads();
-        vec w[WIN];
-#pragma unroll
-        for (int j = 0; j < WIN; j++)
-            w[j] = lds[buf][(px + j) * 8 + lq];
-#pragma unroll
-        for (int j = 0; j < WIN - 1; j++)
-            ring[j] = ring[j + 1];
-        ring[WIN - 1] = OP::h(w);
-        if (yy - PR >= y0) {
-            if (live)
-                vstore<4>(o, OP::v(ring));
-            o += row_elems;
+        for (int rr = 0; rr < WIN; rr++) {
+            const int yy = yb + rr;
+            if (yy <= ylast) {                  // (uniform; no break, so the group unrolls)
+    #pragma unroll
+                for (int n = 0; n < NL; n++)
+                    if (t + n * NT < HX * 8)
+                        lds[buf][t + n * NT] = g[n];
+                if (yy < ylast)
+                    gload(yy + 1);
+                __syncthreads();
+                vec w[WIN];
+    #pragma unroll
+                for (int j = 0; j < WIN; j++)
+                    w[j] = lds[buf][(px + j) * 8 + lq];
+                if constexpr (OP::SYMMETRIC) {
+                    ring[rr] = OP::h(w);
+                } else {
+    #pragma unroll
+                    for (int j = 0; j < WIN - 1; j++)
+                        ring[j] = ring[j + 1];
+                    ring[WIN - 1] = OP::h(w);
+                }
+                if (yy - PR >= y0) {
+                    if constexpr (!WTA) {
+                        if (live)
+                            vstore<4>(o, OP::v(ring));
+                        o += row_elems;
+                    } else {
+                        const vec v = OP::v(ring);
+                        int sb = 0x7FFFFFFF, sd = 0x7FFFFFFF;
+                        if (live) {
+                            float bc = padded[0] ? pw.outside : v[0];
+                            int be = 0;
+    #pragma unroll
+                            for (int e = 1; e < 4; e++) {
+                                float c = padded[e] ? pw.outside : v[e];
+                                if (c < bc) {               // strict: the lowest level wins inside the lane
+                                    bc = c;
+                                    be = e;
+                                }
+                            }
+                            sb = ordered_bits(bc);
+                            sd = pw.d_first + k0 + lq * 4 + be;
+                        }
+                        seg8_min_to_first(sb, sd);
+                        if (lq == 0 && x0 + px < W)
+                            atomicMin(pw.keys + (size_t)(x0 + px) * H + (yy - PR), make_key(sb, sd));
+                    }
+                }
+                buf ^= 1;
+            }
         }
-        buf ^= 1;
     }
+}
+
+__global__ void fill_keys_kernel(long long *keys, size_t n, long long value)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        keys[i] = value;
 }
 
 }  // namespace smk

@@ -100,6 +100,19 @@ class StereoMatcher(StereoParameters):
                 and not self.aggr_subpixel and not self.aggr_collapse
                 and not self.eval_match_quality and self.m_disp_den == 1)
 
+    def _box_dsi_fusable(self):
+        # RawCosts + one AggrBox as smhip_fused_box_dsi (12 instead of 20 bytes per voxel)
+        p = self.m_params
+        return (self.allow_fused and self.aggr_fn == eBox and self.aggr_iter == 1
+                and self.m_disp_den == 1 and p.disp_n >= 33 and p.disp_n % 4 == 0
+                and (p.n_bands == 1 or self.m_pitch % 4 == 0) and not self.eval_match_quality)
+
+    def _min_wta_fusable(self):
+        # AggrMin + PadCosts + OptWTA as smhip_min_pad_wta_keys (the filtered DSI is not written)
+        return (self.allow_fused and self.aggr_minfilter in (3, 5, 7, 9, 11) and self.opt_fn == eWTA
+                and self.m_disp_den == 1 and self.m_params.disp_n % 4 == 0 and not self.refine_subpix
+                and not self.aggr_subpixel and not self.aggr_collapse and not self.eval_match_quality)
+
     def ComputeCorrespondence(self, ref, mtc):
         """ref, mtc: uint8 [H, W, nBands] host arrays.  Returns (disparity, best_cost, depth)."""
         ref = np.ascontiguousarray(ref, np.uint8)
@@ -140,7 +153,10 @@ class StereoMatcher(StereoParameters):
         self.m_disp_n = p.disp_n
         self.m_row_elems = p.width * p.disp_n
         self.d_cost = self._buf("cost", self.m_row_elems * p.height * 4)
-        self.ctx.raw_costs(self.d_ref, self.d_mtc, self.m_pitch, p, self.d_cost, self.m_row_elems)
+        self.m_keys_done = False
+        self.m_raw_deferred = self._box_dsi_fusable()       # raw costs are then made inside AggrBox
+        if not self.m_raw_deferred:
+            self.ctx.raw_costs(self.d_ref, self.d_mtc, self.m_pitch, p, self.d_cost, self.m_row_elems)
 
     def Aggregate(self):  # StcAggregate.cpp:255-365
         p, c = self.m_params, self.ctx
@@ -155,8 +171,12 @@ class StereoMatcher(StereoParameters):
         # iterations per pass over the DSI (smhip_*_run), with the reference's ping-pong of
         # m_cost / m_cost2 (StcDiffusion.cpp:58-63)
         if self.aggr_fn == eBox:
-            for _ in range(self.aggr_iter):
-                c.box_filter(self.d_cost, w, h, nb, re, self.aggr_window_size)
+            if self.m_raw_deferred:
+                c.fused_box_dsi(self.d_ref, self.d_mtc, self.m_pitch, p, self.aggr_window_size, 0, nb,
+                                self.d_cost, re)
+            else:
+                for _ in range(self.aggr_iter):
+                    c.box_filter(self.d_cost, w, h, nb, re, self.aggr_window_size)
         elif self.aggr_fn in (eBinomial, eDiffusion, eMembrane):
             if self.aggr_iter > 0:
                 other = self._buf("cost2", nbytes)
@@ -170,6 +190,12 @@ class StereoMatcher(StereoParameters):
                     self.d_cost = other
         else:
             raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
+        if self.aggr_minfilter > 1 and self._min_wta_fusable():          # :351-365 + OptWTA, no DSI write
+            keys = self._buf("keys", w * h * 8)
+            c.min_pad_wta_keys(self.d_cost, re, p, self.aggr_minfilter, 0, nb, keys)
+            c.keys_decode(keys, w, h, self.d_disp, self.d_best)
+            self.m_keys_done = True
+            return
         if self.aggr_minfilter > 1:                                      # :351-360
             other = self._buf("cost2", nbytes)
             c.min_filter_to(self.d_cost, other, w, h, nb, re, self.aggr_minfilter)
@@ -210,6 +236,8 @@ class StereoMatcher(StereoParameters):
         if self.opt_fn != eWTA:
             raise ValueError("CStereoMatcher::Optimize(): only opt_fn = eWTA is on the device path")
         p = self.m_params
+        if self.m_keys_done:
+            return
         self.ctx.wta(self.d_cost, p.width, p.height, self.m_disp_n, self.m_row_elems, self.d_disp,
                      self.d_best)
 

@@ -122,3 +122,68 @@ def test_full_size_properties(gpu_ctx):
         k = gpu_ctx.download(keys, (w, h), np.int64)
         merged = k if merged is None else np.minimum(merged, k)
     assert np.array_equal((merged & 0xFFFFFFFF).astype(np.int32).T, disp)   # keys are column-major
+
+
+@pytest.mark.parametrize("w,h,b,D,win,sign,fn,mmax,interval", [
+    (70, 40, 1, 36, 9, 1, 1, 1000, 1),
+    (50, 33, 4, 64, 5, 1, 2, 30, 0),
+    (45, 70, 1, 100, 4, -1, 1, 1000, 1),     # even window: generic passes
+    (40, 20, 1, 260, 9, 1, 1, 7, 0),         # two 256-level chunks
+    (64, 36, 1, 128, 13, 1, 2, 1000, 1),     # static pass A, generic pass B
+])
+def test_fused_box_dsi(gpu_ctx, oracle, w, h, b, D, win, sign, fn, mmax, interval):
+    """smhip_fused_box_dsi == smhip_raw_costs + smhip_box_filter (== oracle), whole DSI, bit for
+    bit, including the positions PadCosts will overwrite later; then min filter + pad + WTA as
+    smhip_min_pad_wta_keys == the staged oracle pipeline of exp2."""
+    ref, mtc = synth.noise_pair(w, h, b, seed=synth.SEED_NOISE + D)
+    fr, fm = (0, 1) if sign > 0 else (1, 0)
+    po = oracle.make_params(w, h, b, disp_max=D - 1, frame_ref=fr, frame_match=fm, match_fn=fn,
+                            match_max=mmax, match_interval=interval, aggr_window_size=win)
+    want = oracle.box_filter(oracle.raw_costs(ref, mtc, po), win)
+    p = capi.match_params(w, h, b, D, frame_diff_sign=sign, match_fn=fn, match_max=mmax,
+                          match_interval=interval)
+    d_ref, d_mtc = gpu_ctx.upload(ref), gpu_ctx.upload(mtc)
+    cost = gpu_ctx.alloc(w * h * D * 4)
+    gpu_ctx.fused_box_dsi(d_ref, d_mtc, w * b, p, win, 0, D, cost, w * D)
+    util.assert_bit_equal(gpu_ctx.download(cost, (h, w, D), np.float32), want, "fused box DSI")
+    for mf in (3, 9):
+        wd, wb = oracle.wta(oracle.pad_costs(oracle.min_filter(want, mf), po))
+        keys = gpu_ctx.alloc(w * h * 8)
+        disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
+        gpu_ctx.min_pad_wta_keys(cost, w * D, p, mf, 0, D, keys)
+        gpu_ctx.keys_decode(keys, w, h, disp, best)
+        assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
+        util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "min+pad+wta best")
+    # a disparity slab of the same volume
+    d0, n = 8, D - 12 - (D - 12) % 4
+    if n >= 33:
+        slab = gpu_ctx.alloc(w * h * n * 4)
+        gpu_ctx.fused_box_dsi(d_ref, d_mtc, w * b, p, win, d0, n, slab, w * n)
+        util.assert_bit_equal(gpu_ctx.download(slab, (h, w, n), np.float32), want[:, :, d0:d0 + n], "slab")
+        keys = gpu_ctx.alloc(w * h * 8)
+        gpu_ctx.min_pad_wta_keys(slab, w * n, p, 5, d0, n, keys)
+        k = gpu_ctx.download(keys, (w, h), np.int64).T
+        padded = oracle.pad_costs(oracle.min_filter(want, 5), po)[:, :, d0:d0 + n]
+        wd, wb = oracle.wta(padded)
+        from stereomatch_amd import sharding
+        gd, gb = sharding.decode_keys(k)
+        assert np.array_equal(gd, wd + d0)
+        util.assert_bit_equal(gb, wb, "slab keys")
+
+
+def test_exp2_pipeline_fused_equals_staged(gpu_ctx, oracle):
+    """The exp2 configuration (box 9x9 + 9x9 min filter + WTA) at D = 64 through the matcher:
+    fused route (smhip_fused_box_dsi + smhip_min_pad_wta_keys) == staged route == oracle."""
+    w, h, D = 200, 120, 64
+    left, right, _ = synth.scene_pair(w, h, D)
+    kw = dict(disp_min=0, disp_max=D - 1, match_fn=2, match_max=20, aggr_window_size=9, aggr_minfilter=9)
+    po = oracle.make_params(w, h, 1, **kw)
+    odisp, obest, odepth, _ = oracle.compute_correspondence(left, right, po)
+    for fused in (True, False):
+        m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+        m.allow_fused = fused
+        disp, best, depth = m.ComputeCorrespondence(left, right)
+        assert m.m_keys_done == fused and m.m_raw_deferred == fused
+        assert np.array_equal(disp, odisp), fused
+        util.assert_bit_equal(best, obest, "best cost")
+        assert np.array_equal(depth, odepth)
