@@ -439,6 +439,22 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     return SMHIP_OK;
 }
 
+// Rows per workgroup of the tile kernels: 128 for large volumes (6 % re-computed halo rows), down
+// to 16 for small ones so that a launch still has on the order of a thousand workgroups.
+static int tile_seglen(int w, int h, int nb)
+{
+    if (const char *e = getenv("SMHIP_TSEG")) {      // test knob: force a segment length
+        int v = atoi(e);
+        if (v >= 8 && v <= 4096)
+            return v;
+    }
+    long tiles = (long)((w + 31) / 32) * ((nb + 31) / 32);
+    int seg = 128;
+    while (seg > 16 && tiles * ((h + seg - 1) / seg) < 2048)
+        seg >>= 1;
+    return seg;
+}
+
 static dim3 walk_grid(int w, int nb, int h, int vec, int seglen)
 {
     long threads = ((long)w * nb + vec - 1) / vec;
@@ -468,7 +484,7 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
             smk::minfilter_walk_kernel<1, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
                                                                             row_elems, seglen);     \
     } while (0)
-    const int tseg = h >= 1024 ? 128 : 64;
+    const int tseg = tile_seglen(w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
 #define LAUNCH_TMIN(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32><<<tgrid, 256, 0, ctx->stream>>>( \
         d_src, d_dst, w, nb, h, row_elems, tseg)
@@ -549,7 +565,7 @@ int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, in
     const int seglen = 64;
     int vec = walk_vec(nb, row_elems, d_src, d_dst, nullptr);
     dim3 grid = walk_grid(w, nb, h, vec, seglen);
-    const int tseg = h >= 1024 ? 128 : 64;
+    const int tseg = tile_seglen(w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
     if (vec == 4 && tgrid.y <= 65535 && tgrid.z <= 65535)
         smk::tile_walk_kernel<smk::BinomOp, 32><<<tgrid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h,
@@ -627,7 +643,7 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
     const bool mem = beta > 0.0f;
     float *cur = d_a, *oth = d_b;
     *result_in_b = 0;
-    const int tseg = h >= 1024 ? 128 : 64;
+    const int tseg = tile_seglen(w, h, nb);
     const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
     if (walk_vec(nb, row_elems, d_a, d_b, mem ? d_cost0 : nullptr) != 4 || gy > 65535 || gz > 65535) {
         for (int i = 0; i < n_iter; i++) {          // unaligned shapes: one iteration per pass
@@ -679,7 +695,7 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         return fail(SMHIP_EINVAL, "negative iteration count");
     float *cur = d_a, *oth = d_b;
     *result_in_b = 0;
-    const int tseg = h >= 1024 ? 128 : 64;
+    const int tseg = tile_seglen(w, h, nb);
     const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
     if (walk_vec(nb, row_elems, d_a, d_b, nullptr) != 4 || gy > 65535 || gz > 65535) {
         for (int i = 0; i < n_iter; i++) {
@@ -886,11 +902,13 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     // padded slab width Dp: a power of two below 64 (narrow kernels), else 64 / 128 / 256 with
     // 1 / 2 / 4 levels per lane, else chunks of 256 levels
     int Dp, CH;
-    if (d_count <= 32) {
-        Dp = 2;
+    const bool img_aligned = p->n_bands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
+                                                 ((uintptr_t)d_mtc & 3) == 0);
+    if (d_count <= 32 && !(img_aligned && !getenv("SMHIP_NARROW"))) {
+        Dp = 2;                      // general-shape kernels (4-band images with unaligned rows)
         while (Dp < d_count) Dp <<= 1;
         CH = Dp;
-    } else if (d_count <= 64) {
+    } else if (d_count <= 64) {      // also narrow slabs: lanes beyond d_count idle, T stays sparse
         Dp = CH = 64;
     } else if (d_count <= 128) {
         Dp = CH = 128;
@@ -1075,7 +1093,7 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     int w = p->width, h = p->height;
     rc = check_dsi(d_cost, w, h, d_count, row_elems);
     if (rc) return rc;
-    const int tseg = h >= 1024 ? 128 : 64;
+    const int tseg = tile_seglen(w, h, d_count);
     dim3 tgrid((w + 31) / 32, (d_count + 31) / 32, (h + tseg - 1) / tseg);
     if (walk_vec(d_count, row_elems, d_cost, nullptr, nullptr) != 4 || min_window % 2 != 1 || min_window < 3 ||
         min_window > 11 || tgrid.y > 65535 || tgrid.z > 65535)

@@ -321,3 +321,27 @@ def test_multi_iteration_passes(gpu_ctx, oracle, h, w, d, pad, n_iter):
     bufs = (up(gpu_ctx, padded(c)), gpu_ctx.alloc(h * re * 4))
     in_b = gpu_ctx.convolve_14641_run(bufs[0], bufs[1], w, h, d, re, n_iter)
     util.assert_bit_equal(result(bufs, in_b), want, "binomial x%d" % n_iter)
+
+
+def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, monkeypatch):
+    """Large volumes use 128-row segments in the LDS-tiled kernels; force that length on a small
+    volume (SMHIP_TSEG) so the segment logic of the production configuration is covered."""
+    monkeypatch.setenv("SMHIP_TSEG", "128")
+    h, w, d = 300, 40, 8
+    c = util.rand_dsi(h, w, d, 90, "float")
+    src, dst = up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4)
+    gpu_ctx.min_filter_to(src, dst, w, h, d, w * d, 9)
+    util.assert_bit_equal(gpu_ctx.download(dst, (h, w, d), np.float32), oracle.min_filter(c, 9), "min 9")
+    gpu_ctx.convolve_14641_to(src, dst, w, h, d, w * d)
+    util.assert_bit_equal(gpu_ctx.download(dst, (h, w, d), np.float32), oracle.convolve_14641(c), "binomial")
+    want = c
+    for _ in range(4):
+        want = oracle.convolve_14641(want)
+    in_b = gpu_ctx.convolve_14641_run(src, dst, w, h, d, w * d, 4)
+    util.assert_bit_equal(gpu_ctx.download(dst if in_b else src, (h, w, d), np.float32), want, "binomial x4")
+    src = up(gpu_ctx, c)
+    want = c
+    for _ in range(4):
+        want = oracle.diffusion_iter(want, 0.15, 0.0, None)
+    in_b = gpu_ctx.diffusion_run(src, dst, None, w, h, d, w * d, 0.15, 0.0, 4)
+    util.assert_bit_equal(gpu_ctx.download(dst if in_b else src, (h, w, d), np.float32), want, "diffusion x4")
