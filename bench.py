@@ -169,6 +169,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, left, right, args, Dg, win)
+            out["cpu_baseline_all_cores"] = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
         print(json.dumps(out), flush=True)
 
     if world > 1:
@@ -177,24 +178,31 @@ def main():
     ctx.close()
 
 
-def cpu_baseline(np, left, right, args, D, win):
+def cpu_baseline(np, left, right, args, D, win, openmp=False):
     """The CPU oracle (a port of the reference's single-threaded CPU path, bit-identical to it on
-    the tsukuba anchors) on the top `cpu_rows` rows of the same image pair, one core."""
+    the tsukuba anchors) on the top `cpu_rows` rows of the same image pair: one core (like the
+    reference), or -- openmp=True -- the -fopenmp build of the same source on the host cores this
+    process may use (OMP_NUM_THREADS)."""
     from oracle import oracle as O
+    O.use_openmp(openmp)
     rows = min(args.cpu_rows, left.shape[0])
     l, r = np.ascontiguousarray(left[:rows]), np.ascontiguousarray(right[:rows])
     h, w, b = l.shape
     p = O.make_params(w, h, b, disp_min=0, disp_max=D - 1, match_fn=1, match_interval=1,
                       match_max=1000, aggr_window_size=win)
     O.lib()
+    cores = O.threads()
     t0 = time.perf_counter()
     O.compute_correspondence(l, r, p)
     dt = time.perf_counter() - t0
-    return {"value": round(w * h * D / dt / 1e9, 5), "unit": "G pixel*disparity/s", "cores": 1,
+    O.use_openmp(False)
+    return {"value": round(w * h * D / dt / 1e9, 5), "unit": "G pixel*disparity/s", "cores": cores,
             "kind": "port",
-            "sample": "top %d of %d rows of the same %dx%d D=%d pair (%.1f s of CPU work); "
-                      "oracle/sm_oracle.c, gcc -O2, single thread like the reference" % (
-                          rows, left.shape[0], w, left.shape[0], D, dt)}
+            "sample": "top %d of %d rows of the same %dx%d D=%d pair (%.1f s wall); "
+                      "oracle/sm_oracle.c, gcc -O2%s" % (
+                          rows, left.shape[0], w, left.shape[0], D, dt,
+                          " -fopenmp, rows / column blocks over %d threads" % cores if openmp
+                          else ", single thread like the reference")}
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libsm_oracle.so")
+_SO_OMP = os.path.join(_HERE, "_build", "libsm_oracle_omp.so")
 
 
 class Params(C.Structure):
@@ -63,13 +64,27 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
 
 def build(force=False):
     src = [os.path.join(_HERE, f) for f in ("sm_oracle.c", "sm_oracle.h", "Makefile")]
-    if force or not os.path.exists(_SO) or any(
+    if force or not os.path.exists(_SO) or not os.path.exists(_SO_OMP) or any(
             os.path.getmtime(s) > os.path.getmtime(_SO) for s in src):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _SO
 
 
 _lib = None
+
+
+def use_openmp(on=True):
+    """Switches this module to the -fopenmp build of the same source (bench.py's all-cores
+    line; the tests check it gives identical results)."""
+    global _lib, _SO
+    _lib = None
+    _SO = _SO_OMP if on else os.path.join(_HERE, "_build", "libsm_oracle.so")
+
+
+def threads():
+    L = lib()
+    L.smo_threads.restype = C.c_int
+    return int(L.smo_threads())
 
 
 def lib():

@@ -12,6 +12,9 @@
 #include "sm_oracle.h"
 
 #include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -160,11 +163,20 @@ void smo_raw_costs(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
     int interval = p->match_interval ? 1 : 0;        /* :354 */
     float outside = smo_match_outside(p);
     size_t len = (size_t)n * nb;
+    /* Rows are independent (the reference walks them one after the other with one set of line
+     * buffers); with -fopenmp every thread gets its own buffers -- same arithmetic per row. */
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+    {
     int *buf0 = calloc(len * 6, sizeof(int));
     int *buf1 = buf0 + len, *min0 = buf1 + len, *max0 = min0 + len;
     int *min1 = max0 + len, *max1 = min1 + len;
     float *cost1 = calloc((size_t)n, sizeof(float));
 
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
     for (int y = 0; y < h; y++) {
         const uint8_t *r = ref + (size_t)y * img_row_bytes;
         const uint8_t *m = mtc + (size_t)y * img_row_bytes;
@@ -195,6 +207,7 @@ void smo_raw_costs(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
     }
     free(cost1);
     free(buf0);
+    }
 }
 
 /* StcRawCosts.cpp:437-476 */
@@ -203,6 +216,9 @@ void smo_pad_costs(float *cost, long row_elems, const smo_params *p)
     int w = p->width, den = p->disp_den;
     int n = (w - 1) * den + 1;
     float outside = smo_match_outside(p);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int y = 0; y < p->height; y++)
         for (int k = 0; k < p->disp_n; k++) {
             int disp = -p->frame_diff_sign * (den * p->disp_min + k * p->disp_num);
@@ -244,10 +260,22 @@ static void box_lines(const float *src, float *dst, long n_sums, int len, long s
 void smo_box_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,
                     int window, int average)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int y = 0; y < h; y++)                      /* :214-220 */
         box_lines(cost + (size_t)y * row_elems, tmp + (size_t)y * row_elems, nb, w, nb,
                   window, average);
+#ifdef _OPENMP
+    /* the column sums are independent per (x, d): hand each thread a block of them */
+    long n_col = (long)nb * w, blk = 4096;
+#pragma omp parallel for schedule(static)
+    for (long k0 = 0; k0 < n_col; k0 += blk)
+        box_lines(tmp + k0, cost + k0, (n_col - k0 < blk) ? n_col - k0 : blk, h, row_elems, window,
+                  average);
+#else
     box_lines(tmp, cost, (long)nb * w, h, row_elems, window, average);   /* :225-232 */
+#endif
 }
 
 /* ------------------------------------------------------------------------- */
@@ -369,6 +397,9 @@ void smo_diffusion_iter(const float *src, float *dst, const float *cost0,
 void smo_wta(const float *cost, int w, int h, int nb, long row_elems,
              int32_t *disp, float *best_cost)
 {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
     for (int y = 0; y < h; y++) {
         const float *c = cost + (size_t)y * row_elems;
         for (int x = 0; x < w; x++, c += nb) {
@@ -657,4 +688,15 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
     free(mind);
     free(cost);
     return energy;
+}
+
+/* number of threads the row / column loops use: 1 for the plain build (like the reference),
+ * omp_get_max_threads() for the -fopenmp build that bench.py times next to it */
+int smo_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }

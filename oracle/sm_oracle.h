@@ -119,6 +119,10 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
                                    const smo_params *p, int32_t *disp, float *best_cost,
                                    uint8_t *depth, float *fdisp);
 
+/* 1, or the OpenMP thread count of the -fopenmp build (_build/libsm_oracle_omp.so: the same
+ * source, rows / column blocks spread over threads, identical results) */
+int smo_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

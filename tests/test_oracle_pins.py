@@ -163,3 +163,24 @@ def test_wta_and_pad(oracle):
     for k in range(7):
         assert np.all(out[:, :1 + k, k] == o)
         assert np.array_equal(out[:, 1 + k:, k], c[:, 1 + k:, k])
+
+
+def test_openmp_build_is_identical(oracle, tsukuba):
+    """oracle/_build/libsm_oracle_omp.so (bench.py's all-cores CPU line) spreads rows and column
+    blocks over threads; every chain keeps its own serial order, so the bits do not change."""
+    import util
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    grid = dict(util.exp_grid())
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **grid["SSD09"])
+    want = oracle.compute_correspondence(ref, mtc, p)
+    oracle.use_openmp(True)
+    try:
+        assert oracle.threads() >= 1
+        got = oracle.compute_correspondence(ref, mtc, p)
+    finally:
+        oracle.use_openmp(False)
+    assert oracle.threads() == 1
+    for a, g in zip(want[:3], got[:3]):
+        assert a.tobytes() == g.tobytes()
+    assert want[3] == got[3] == util.anchors()["reference"]["final_energy"]["SSD09"]
