@@ -81,6 +81,11 @@ int smhip_memcpy2d_d2h(smhip_ctx *ctx, void *h_dst, size_t h_pitch, const void *
 
 /* ---- stage operators ---- */
 
+/* PreProcess (StcPreProcess.cpp:49-55): n_iter times the separable uchar blur (121 in x, 14641 in
+ * y, replicate border, truncating conversion) on a device image, in place. */
+int smhip_preprocess_blur(smhip_ctx *ctx, uint8_t *d_img, size_t img_pitch, int w, int h,
+                          int n_bands, int n_iter);
+
 /* m_match_outside (StcRawCosts.cpp:365-367) */
 float smhip_match_outside(const smhip_match_params *p);
 

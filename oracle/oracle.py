@@ -30,6 +30,7 @@ class Params(C.Structure):
         ("opt_grad_penalty", C.c_float),
         ("disp_step", C.c_float), ("disp_scale", C.c_float),
         ("aggr_subpixel", C.c_int), ("aggr_collapse", C.c_int), ("refine_subpix", C.c_int),
+        ("preproc_blur_iter", C.c_int),
     ]
 
 
@@ -53,7 +54,7 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
         diff_lambda=0.15, diff_beta=0.5,
         opt_smoothness=1.0, opt_grad_thresh=5.0, opt_grad_penalty=1.0,
         disp_step=float(step), disp_scale=disp_scale,
-        aggr_subpixel=0, aggr_collapse=0, refine_subpix=0,
+        aggr_subpixel=0, aggr_collapse=0, refine_subpix=0, preproc_blur_iter=0,
     )
     for k, v in kw.items():
         if not hasattr(p, k):
@@ -120,7 +121,8 @@ def lib():
                                    C.c_long, C.c_float, fp, fp]
         L.smo_refine.argtypes = [fp, fp, i32, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float,
                                  C.c_int, C.c_int, fp]
-        for name in ("smo_subpixel_fit", "smo_collapse", "smo_refine"):
+        L.smo_preprocess_blur.argtypes = [u8, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+        for name in ("smo_subpixel_fit", "smo_collapse", "smo_refine", "smo_preprocess_blur"):
             getattr(L, name).restype = None
         for name in ("smo_raw_costs", "smo_box_filter", "smo_min_filter", "smo_convolve_14641",
                      "smo_diffusion_iter", "smo_pad_costs", "smo_wta", "smo_aggregate",
@@ -274,3 +276,10 @@ def refine(cost, mind, disp, step, disp_min, mode):
     lib().smo_refine(_fp(c), _fp(m) if m is not None else None, _i32(dd), w, h, d, w * d, step,
                      disp_min, mode, _fp(out))
     return out
+
+
+def preprocess_blur(img, iters):
+    a = np.array(_img(img), copy=True)
+    h, w, b = a.shape
+    lib().smo_preprocess_blur(_u8(a), w * b, w, h, b, iters)
+    return a

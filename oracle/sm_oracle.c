@@ -632,6 +632,43 @@ void smo_depth_from_float(const float *fdisp, int n, const smo_params *p, uint8_
     }
 }
 
+/* StcPreProcess.cpp:49-55: ConvolveSeparable<uchar>(img, img, 121, 14641) iterated.  Horizontal
+ * 3-tap pass to a uchar image, then vertical 5-tap pass to a uchar image (Convolve.cpp:224-225);
+ * sums start at 0 and add taps in order (:100-107); replicate border (TrimIndex :42-43); float ->
+ * uchar clips to [0,255] and truncates (Convert.cpp:41-45). */
+void smo_preprocess_blur(uint8_t *img, long row_bytes, int w, int h, int nb, int iters)
+{
+    static const float k121[3] = {0.25f, 0.5f, 0.25f};   /* Convolve.cpp:289 */
+    uint8_t *tmp = malloc((size_t)row_bytes * h);
+    for (int it = 0; it < iters; it++) {
+        for (int y = 0; y < h; y++) {
+            const uint8_t *s = img + (size_t)y * row_bytes;
+            uint8_t *d = tmp + (size_t)y * row_bytes;
+            for (int x = 0; x < w; x++)
+                for (int b = 0; b < nb; b++) {
+                    float sum = 0.0f;
+                    for (int l = 0; l < 3; l++)
+                        sum += k121[l] * (float)s[clampi(x + l - 1, w) * nb + b];
+                    float v = sum > 0.0f ? sum : 0.0f;           /* __max(src, minVal) */
+                    v = v < 255.0f ? v : 255.0f;                 /* __min(.., maxVal) */
+                    d[x * nb + b] = (uint8_t)v;
+                }
+        }
+        for (int y = 0; y < h; y++) {
+            uint8_t *d = img + (size_t)y * row_bytes;
+            for (int i = 0; i < w * nb; i++) {
+                float sum = 0.0f;
+                for (int k = 0; k < 5; k++)
+                    sum += k14641[k] * (float)tmp[(size_t)clampi(y + k - 2, h) * row_bytes + i];
+                float v = sum > 0.0f ? sum : 0.0f;
+                v = v < 255.0f ? v : 255.0f;
+                d[i] = (uint8_t)v;
+            }
+        }
+    }
+    free(tmp);
+}
+
 float smo_compute_correspondence(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
                                  const smo_params *p, int32_t *disp, float *best_cost,
                                  uint8_t *depth)
@@ -651,6 +688,17 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
     int32_t *d = disp ? disp : malloc(n_pix * sizeof(int32_t));
     float *fd = fdisp ? fdisp : malloc(n_pix * sizeof(float));
     float step = p->disp_step;
+    uint8_t *pre = NULL;
+    if (p->preproc_blur_iter > 0) {                      /* StereoMatcher.cpp:165, on copies (:103-106) */
+        size_t img = (size_t)img_row_bytes * h;
+        pre = malloc(2 * img);
+        memcpy(pre, ref, img);
+        memcpy(pre + img, mtc, img);
+        smo_preprocess_blur(pre, img_row_bytes, w, h, p->n_bands, p->preproc_blur_iter);
+        smo_preprocess_blur(pre + img, img_row_bytes, w, h, p->n_bands, p->preproc_blur_iter);
+        ref = pre;                                       /* the energy's smoothness term sees it too */
+        mtc = pre + img;
+    }
 
     smo_raw_costs(ref, mtc, img_row_bytes, p, cost, row_elems);
     smo_aggregate(cost, row_elems, p);
@@ -687,6 +735,7 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
         free(fd);
     free(mind);
     free(cost);
+    free(pre);
     return energy;
 }
 

@@ -51,6 +51,8 @@ typedef struct smo_params {
     float disp_step, disp_scale;
     /* sub-pixel stages, StereoParameters.h:118-120,179 */
     int aggr_subpixel, aggr_collapse, refine_subpix;
+    /* StereoParameters.h:57-58 */
+    int preproc_blur_iter;
 } smo_params;
 
 /* StcRawCosts.cpp:364-367 */
@@ -98,6 +100,9 @@ void smo_depth_image(const int32_t *disp, int n, const smo_params *p, uint8_t *d
 float smo_compute_correspondence(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
                                  const smo_params *p, int32_t *disp, float *best_cost,
                                  uint8_t *depth);
+
+/* StcPreProcess.cpp:49-55 (in place) */
+void smo_preprocess_blur(uint8_t *img, long row_bytes, int w, int h, int nb, int iters);
 
 /* StcAggregate.cpp:66-132 (in place; mind/cert: same shape as cost) */
 void smo_subpixel_fit(float *cost, float *mind, float *cert, int w, int h, int nb,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
-    "smhip_fused_box_dsi", "smhip_min_pad_wta_keys",
+    "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     L.smhip_convolve_14641_run.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, C.POINTER(ci)]
     L.smhip_fused_box_dsi.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp, sz]
     L.smhip_min_pad_wta_keys.argtypes = [vp, vp, sz, pp, ci, ci, ci, vp]
+    L.smhip_preprocess_blur.argtypes = [vp, vp, sz, ci, ci, ci, ci]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
@@ -208,6 +209,9 @@ class Context:
         return out
 
     # -- operators (arguments as in include/smhip.h)
+    def preprocess_blur(self, d_img, img_pitch, w, h, nb, n_iter):
+        self._chk(self.L.smhip_preprocess_blur(self.h, _ptr(d_img), img_pitch, w, h, nb, n_iter))
+
     def match_outside(self, p):
         return float(self.L.smhip_match_outside(C.byref(p)))
 

@@ -166,8 +166,19 @@ void CStereoMatcher::ComputeCorrespondence()
 
 void CStereoMatcher::PreProcess()
 {
-    if (preproc_blur_iter > 0 || preproc_addnoise_stddev > 0.0f)   // StcPreProcess.cpp:39-55
-        throw CError("PreProcess: input blur / noise is not part of the device hot path");
+    if (preproc_addnoise_stddev > 0.0f)                       // StcPreProcess.cpp:33-37
+        throw CError("PreProcess: additive noise not yet implemented");
+    if (preproc_blur_iter <= 0)
+        return;
+    if (verbose >= eVerboseProgress)
+        fprintf(stderr, "- pre-process: binomial 121 filter iterated %d times\n", preproc_blur_iter);
+    // blur the device copies of both frames (:49-55); the blurred reference comes back to the host
+    // because the smoothness term of the energy reads it (StcOptimize.cpp:103-116)
+    Check(smhip_preprocess_blur(m_ctx, (uint8_t *)m_dev[B_REF], m_reference.RowBytes(), m_mp.width, m_mp.height,
+                                m_mp.n_bands, preproc_blur_iter));
+    Check(smhip_preprocess_blur(m_ctx, (uint8_t *)m_dev[B_MTC], m_matching.RowBytes(), m_mp.width, m_mp.height,
+                                m_mp.n_bands, preproc_blur_iter));
+    Check(smhip_memcpy_d2h(m_ctx, m_reference.Data(), m_dev[B_REF], m_reference.ImageSize()));
 }
 
 void CStereoMatcher::RawCosts()

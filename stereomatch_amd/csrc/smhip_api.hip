@@ -335,6 +335,26 @@ int smhip_memcpy2d_d2h(smhip_ctx *ctx, void *h_dst, size_t h_pitch, const void *
     return SMHIP_OK;
 }
 
+int smhip_preprocess_blur(smhip_ctx *ctx, uint8_t *d_img, size_t img_pitch, int w, int h, int nb, int n_iter)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!d_img || w < 1 || h < 1 || nb < 1 || img_pitch < (size_t)w * nb || n_iter < 0)
+        return fail(SMHIP_EINVAL, "PreProcess: bad image arguments");
+    if (n_iter == 0)
+        return SMHIP_OK;
+    void *tmp = nullptr;
+    rc = ws_get(ctx, WS_BT, img_pitch * (size_t)h, &tmp);
+    if (rc) return rc;
+    dim3 grid((w * nb + 255) / 256, h);
+    for (int i = 0; i < n_iter; i++) {
+        smk::blur121_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_img, (uint8_t *)tmp, img_pitch, w, h, nb);
+        smk::blur14641_v_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)tmp, d_img, img_pitch, w, h, nb);
+    }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
 float smhip_match_outside(const smhip_match_params *p)
 {
     return p ? (float)outside_of(p) : 0.0f;

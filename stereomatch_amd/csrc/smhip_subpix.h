@@ -146,4 +146,44 @@ __global__ void pad_costs_subpix_kernel(float *cost, size_t row_elems, int W, in
         cost[(size_t)y * row_elems + e] = outside;
 }
 
+// PreProcess (StcPreProcess.cpp:49-55): ConvolveSeparable<uchar>(img, img, 121, 14641) -- a
+// horizontal 3-tap pass and a vertical 5-tap pass, each rounded down to uchar (Convolve.cpp:
+// 224-225, Convert.cpp:41-45).  One thread per byte; images are a few MB.
+__device__ __forceinline__ uint8_t to_uchar_clip(float v)
+{
+    v = v > 0.0f ? v : 0.0f;
+    v = v < 255.0f ? v : 255.0f;
+    return (uint8_t)v;
+}
+
+__global__ void blur121_h_kernel(const uint8_t *src, uint8_t *dst, size_t pitch, int W, int H, int nb)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;   // x*nb + band
+    int y = blockIdx.y;
+    if (i >= W * nb)
+        return;
+    int x = i / nb, b = i - x * nb;
+    const uint8_t *r = src + (size_t)y * pitch;
+    float sum = 0.0f;
+    sum += 0.25f * (float)r[clampi(x - 1, W) * nb + b];
+    sum += 0.5f * (float)r[i];
+    sum += 0.25f * (float)r[clampi(x + 1, W) * nb + b];
+    dst[(size_t)y * pitch + i] = to_uchar_clip(sum);
+}
+
+__global__ void blur14641_v_kernel(const uint8_t *src, uint8_t *dst, size_t pitch, int W, int H, int nb)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (i >= W * nb)
+        return;
+    float sum = 0.0f;
+    sum += 0.0625f * (float)src[(size_t)clampi(y - 2, H) * pitch + i];
+    sum += 0.25f * (float)src[(size_t)clampi(y - 1, H) * pitch + i];
+    sum += 0.375f * (float)src[(size_t)y * pitch + i];
+    sum += 0.25f * (float)src[(size_t)clampi(y + 1, H) * pitch + i];
+    sum += 0.0625f * (float)src[(size_t)clampi(y + 2, H) * pitch + i];
+    dst[(size_t)y * pitch + i] = to_uchar_clip(sum);
+}
+
 }  // namespace smk

@@ -49,6 +49,7 @@ class StereoParameters:
         self.opt_fn = eWTA
         self.refine_subpix = 0
         self.eval_match_quality = 0
+        self.preproc_blur_iter = 0
 
 
 class StereoMatcher(StereoParameters):
@@ -129,6 +130,7 @@ class StereoMatcher(StereoParameters):
         c = self.ctx
         c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_ref.ptr, ref.ctypes.data, ref.nbytes))
         c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_mtc.ptr, mtc.ctypes.data, mtc.nbytes))
+        self.PreProcess()
         self.d_disp = self._buf("disp", w * h * 4)
         self.d_best = self._buf("best", w * h * 4)
         self.used_fused = self._fusable()
@@ -147,6 +149,13 @@ class StereoMatcher(StereoParameters):
             self.m_float_disparity = self.Refine()
         best = c.download(self.d_best, (h, w), np.float32)
         return disp, best, self._depth_image(self.m_float_disparity)
+
+    def PreProcess(self):  # StcPreProcess.cpp:31-56, on the device copies of the two frames
+        if self.preproc_blur_iter > 0:
+            p = self.m_params
+            for d_img in (self.d_ref, self.d_mtc):
+                self.ctx.preprocess_blur(d_img, self.m_pitch, p.width, p.height, p.n_bands,
+                                         self.preproc_blur_iter)
 
     def RawCosts(self):  # StcRawCosts.cpp:229
         p = self.m_params

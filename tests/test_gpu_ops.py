@@ -345,3 +345,18 @@ def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, monkeypatch):
         want = oracle.diffusion_iter(want, 0.15, 0.0, None)
     in_b = gpu_ctx.diffusion_run(src, dst, None, w, h, d, w * d, 0.15, 0.0, 4)
     util.assert_bit_equal(gpu_ctx.download(dst if in_b else src, (h, w, d), np.float32), want, "diffusion x4")
+
+
+@pytest.mark.parametrize("w,h,b,iters", [(37, 11, 1, 1), (40, 9, 4, 3), (5, 3, 1, 2)])
+def test_preprocess_blur(gpu_ctx, oracle, w, h, b, iters):
+    """PreProcess (StcPreProcess.cpp:49-55): uchar 121 x 14641 blur, truncating, replicate border;
+    rows padded to 8 bytes keep their padding.  Parity unpinned (oracle only)."""
+    img, _ = synth.noise_pair(w, h, b, seed=7 + iters)
+    pitch = (w * b + 7) & ~7
+    host = np.full((h, pitch), 77, np.uint8)
+    host[:, :w * b] = img.reshape(h, w * b)
+    d = up(gpu_ctx, host)
+    gpu_ctx.preprocess_blur(d, pitch, w, h, b, iters)
+    got = gpu_ctx.download(d, (h, pitch), np.uint8)
+    assert np.array_equal(got[:, :w * b].reshape(h, w, b), oracle.preprocess_blur(img, iters))
+    assert np.all(got[:, w * b:] == 77)

@@ -108,3 +108,17 @@ def test_subpixel_stages_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
     assert np.array_equal(depth, odepth)
     if kw.get("refine_subpix") and (kw.get("aggr_subpixel") or not kw.get("aggr_collapse")):
         assert np.any(m.m_float_disparity != np.round(m.m_float_disparity * 4) / 4)
+
+
+def test_preprocess_blur_pipeline(gpu_ctx, tsukuba, oracle):
+    """preproc_blur_iter 2 in front of the SSD / 9x9 box / WTA run (oracle only: parity unpinned)."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    kw = dict(preproc_blur_iter=2, match_fn=2, aggr_window_size=9)
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+    odisp, obest, odepth, _ = oracle.compute_correspondence(ref, mtc, p)
+    for fused in (True, False):
+        m, disp, best, depth = run(gpu_ctx, tsukuba, kw, fused)
+        util.assert_bit_equal(disp, odisp, "disparity")
+        util.assert_bit_equal(best, obest, "best cost")
+        assert np.array_equal(depth, odepth)
