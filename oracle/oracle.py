@@ -34,6 +34,20 @@ class Params(C.Structure):
     ]
 
 
+class Eval(C.Structure):
+    """smo_eval with the defaults of StereoParameters.cpp:87-99."""
+    _fields_ = [("ignore_border", C.c_int), ("bad_thresh", C.c_float), ("disp_gap", C.c_float),
+                ("textureless_width", C.c_int), ("textureless_thresh", C.c_float),
+                ("discont_width", C.c_int)]
+
+
+class EvalOut(C.Structure):
+    _fields_ = [("rms", C.c_float * 6), ("bad", C.c_float * 6), ("fraction_matched", C.c_float)]
+
+
+EVAL_NAMES = ("all", "nonocc", "occ", "textured", "textureless", "discont")
+
+
 def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
                 frame_ref=0, frame_match=1, disp_scale=1.0, **kw):
     """Defaults of ReInitializeAlgParams (StereoParameters.cpp:55-116) and the
@@ -283,3 +297,30 @@ def preprocess_blur(img, iters):
     h, w, b = a.shape
     lib().smo_preprocess_blur(_u8(a), w * b, w, h, b, iters)
     return a
+
+
+def evaluate(fdisp, truth, ref, p, verbose_summary=True, **kw):
+    """Returns {'rms_error_all': ..., 'bad_pixels_all': ..., ..., 'fraction_matched': ...}."""
+    e = Eval(ignore_border=0, bad_thresh=1.0, disp_gap=2.0, textureless_width=3,
+             textureless_thresh=4.0, discont_width=9)
+    for k, v in kw.items():
+        if not hasattr(e, k):
+            raise KeyError(k)
+        setattr(e, k, v)
+    ref = _img(ref)
+    h, w, b = ref.shape
+    fd = np.ascontiguousarray(fdisp, np.float32)
+    tr = np.ascontiguousarray(truth, np.uint8).reshape(h, w)
+    out = EvalOut()
+    L = lib()
+    L.smo_evaluate.restype = None
+    L.smo_evaluate.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_long,
+                               C.POINTER(Params), C.POINTER(Eval), C.c_int, C.POINTER(EvalOut)]
+    L.smo_evaluate(_fp(fd), _u8(tr), _u8(ref), w * b, C.byref(p), C.byref(e), int(verbose_summary),
+                   C.byref(out))
+    res = {}
+    for i, nme in enumerate(EVAL_NAMES):
+        res["rms_error_" + nme] = float(out.rms[i])
+        res["bad_pixels_" + nme] = float(out.bad[i])
+    res["fraction_matched"] = float(out.fraction_matched)
+    return res

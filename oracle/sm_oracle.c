@@ -749,3 +749,204 @@ int smo_threads(void)
     return 1;
 #endif
 }
+
+/* ------------------------------------------------------------------------- */
+/* evaluator: StcEvaluate.cpp:42-587 + ForwardWarp (Warp1D.cpp:25-128)        */
+
+#define SMO_ROUND(x) ((int)((x) >= 0 ? (x) + .5 : (x) - .5))    /* Warp1D.cpp:23 */
+
+/* Warp1D.cpp:25-56, one band; clip = uchar destination (0..255, round_offset 0.5) */
+static void draw_line_f(const float *s1, const float *s2, float *dst, float x1, float x2, int w)
+{
+    if (x2 < x1)
+        return;
+    int i0 = imax(0, SMO_ROUND(x1));
+    int i1 = imin(w - 1, SMO_ROUND(x2));
+    float iden = 1.0 / (x2 - x1 + (x2 == x1));
+    for (int i = i0; i <= i1; i++) {
+        float f = (i - x1) * iden;
+        float v1 = s1[0], v2 = s2[0];
+        float v = v1 + f * (v2 - v1);
+        dst[i] = (float)(v + 0.0f);
+    }
+}
+
+static void draw_line_u8(const uint8_t *s1, const uint8_t *s2, uint8_t *dst, float x1, float x2, int w)
+{
+    if (x2 < x1)
+        return;
+    int i0 = imax(0, SMO_ROUND(x1));
+    int i1 = imin(w - 1, SMO_ROUND(x2));
+    float iden = 1.0 / (x2 - x1 + (x2 == x1));
+    for (int i = i0; i <= i1; i++) {
+        float f = (i - x1) * iden;
+        float v1 = s1[0], v2 = s2[0];
+        float v = v1 + f * (v2 - v1);
+        float r = v + 0.5f;
+        r = r > 0 ? r : 0;                           /* __max(v + round_offset, minVal) */
+        r = r < 255 ? r : 255;                       /* __min(.., maxVal) */
+        dst[i] = (uint8_t)r;
+    }
+}
+
+/* Warp1D.cpp:58-128 for one row; `is_u8` selects the uchar instantiation */
+static void forward_warp_row(const void *src, void *dst, const float *dp, int w, float d_scale,
+                             float disp_gap, int is_u8)
+{
+    int xstart = d_scale > 0 ? 0 : w - 1, xend = d_scale > 0 ? w : -1, xincr = d_scale > 0 ? 1 : -1;
+    const float *psf = src;
+    float *pdf = dst;
+    const uint8_t *psu = src;
+    uint8_t *pdu = dst;
+    for (int x = xstart; x != xend; x += xincr) {
+        int x2 = x + xincr;
+        int draw = 0;
+        if (x2 != xend) {                            /* dp[x2] is only read inside the row */
+            float d_diff = fabsf(dp[x] - dp[x2]);
+            draw = d_diff < disp_gap;
+        }
+        float d = d_scale * dp[x];
+        if (draw) {
+            float d2 = d_scale * dp[x2];
+            if (xincr > 0) {
+                if (is_u8) draw_line_u8(&psu[x], &psu[x2], pdu, x - d, x2 - d2, w);
+                else       draw_line_f(&psf[x], &psf[x2], pdf, x - d, x2 - d2, w);
+            } else {                                 /* (x2 - d, x - d2) as written at :115-117 */
+                if (is_u8) draw_line_u8(&psu[x2], &psu[x], pdu, x2 - d, x - d2, w);
+                else       draw_line_f(&psf[x2], &psf[x], pdf, x2 - d, x - d2, w);
+            }
+            continue;
+        }
+        int xx = x - SMO_ROUND(d);
+        if (xx >= 0 && xx < w) {
+            if (is_u8) pdu[xx] = psu[x];
+            else       pdf[xx] = psf[x];
+        }
+    }
+}
+
+void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                  const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out)
+{
+    int w = p->width, h = p->height, nB = p->n_bands;
+    size_t n = (size_t)w * h;
+    float *trud = malloc(n * sizeof(float));
+    float *fwd = malloc(n * sizeof(float));
+    uint8_t *white = malloc(n), *occ = calloc(n, 1), *texl = malloc(n), *disc = malloc(n);
+    float *sq = calloc(n, sizeof(float)), *tmp = malloc(n * sizeof(float));
+    float *dd = calloc(n, sizeof(float));
+
+    /* StereoMatcher.cpp:125: m_true_disparity = truth / disp_scale + disp_min (Convert.cpp:31-40) */
+    {
+        float scale = 1.0f / p->disp_scale, offset = (float)p->disp_min;
+        for (size_t i = 0; i < n; i++)
+            trud[i] = (scale != 1.0f || offset != 0.0f) ? truth[i] * scale + offset : (float)truth[i];
+    }
+
+    /* ComputeOcclusion(frame_match), StcEvaluate.cpp:42-79 */
+    float shift = (float)p->frame_diff_sign;         /* (frame_match - frame_ref) / |m_frame_diff| */
+    const float invalid_depth = -9999.0f;
+    for (size_t i = 0; i < n; i++)
+        fwd[i] = invalid_depth;
+    for (int y = 0; y < h; y++)
+        forward_warp_row(trud + (size_t)y * w, fwd + (size_t)y * w, trud + (size_t)y * w, w, shift,
+                         e->disp_gap, 0);
+    for (size_t i = 0; i < n; i++)
+        white[i] = (fwd[i] == invalid_depth) ? 0 : 255;
+    for (int y = 0; y < h; y++)
+        forward_warp_row(white + (size_t)y * w, occ + (size_t)y * w, fwd + (size_t)y * w, w, -shift,
+                         e->disp_gap, 1);
+    /* ComputeOcclusions, :86-107: black borders, then occlusion = 255 - visibility */
+    int b = e->ignore_border;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            uint8_t *o = &occ[(size_t)y * w + x];
+            if (x < b || x >= w - b || y < b || y >= h - b)
+                *o = 0;
+            *o = (uint8_t)(*o * -1.0f + 255.0f);
+        }
+
+    /* ComputeTextureless, :110-157 */
+    {
+        int nC = nB - (nB > 1);
+        for (int y = 0; y < h; y++) {
+            const uint8_t *q = ref + (size_t)y * img_row_bytes;
+            float *s = sq + (size_t)y * w;
+            for (int x = 0; x < w - 1; x++, q += nB) {
+                float sum2 = 0;
+                for (int c = 0; c < nC; c++) {
+                    float diff = (int)q[c] - (int)q[c + nB];
+                    sum2 += diff * diff;
+                }
+                sum2 /= (float)nC;
+                s[x + 1] = sum2;
+                if (x == 0)
+                    s[x] = sum2;
+                s[x] = sum2 > s[x] ? sum2 : s[x];
+            }
+        }
+        if (e->textureless_width > 0)
+            smo_box_filter(sq, tmp, w, h, 1, w, e->textureless_width, 1);
+        float thr = e->textureless_thresh * e->textureless_thresh;
+        for (size_t i = 0; i < n; i++)
+            texl[i] = (sq[i] < thr) ? 255 : 0;
+    }
+
+    /* ComputeDisparityDiscont, :190-244 (int image; sums of 255s are exact in float) */
+    {
+        int bor = e->ignore_border + 1;
+        for (int y = 0; y < h - 1; y++) {
+            if (y < bor || y >= h - bor)
+                continue;
+            const float *p0 = trud + (size_t)y * w, *p1 = p0 + w;
+            float *d0 = dd + (size_t)y * w, *d1 = d0 + w;
+            for (int x = bor; x < w - bor - 1; x++) {
+                if (fabsf(p0[x] - p0[x + 1]) >= e->disp_gap)
+                    d0[x] = d0[x + 1] = 255;
+                if (fabsf(p0[x] - p1[x]) >= e->disp_gap)
+                    d0[x] = d1[x] = 255;
+            }
+        }
+        if (e->discont_width > 0)
+            smo_box_filter(dd, tmp, w, h, 1, w, e->discont_width, 0);
+        for (size_t i = 0; i < n; i++)
+            disc[i] = (dd[i] != 0) ? 255 : 0;
+    }
+
+    /* ComputeDisparityErrors, :373-560 (m_status is empty after WTA: all pixels count) */
+    float ssd[6] = {0, 0, 0, 0, 0, 0};               /* all, nonocc, occ, textured, textureless, discont */
+    int bad[6] = {0, 0, 0, 0, 0, 0}, cnt[6] = {0, 0, 0, 0, 0, 0};
+    int total_all = 0;
+    for (int y = b; y < h - b; y++)
+        for (int x = b; x < w - b; x++) {
+            size_t i = (size_t)y * w + x;
+            float diff = fdisp[i] - trud[i];
+            total_all++;
+            int is_bad = fabs(diff) > e->bad_thresh;
+#define SMO_ACC(k) do { ssd[k] += diff * diff; bad[k] += is_bad; cnt[k]++; } while (0)
+            SMO_ACC(0);
+            if (occ[i] > 1) {
+                SMO_ACC(2);
+            } else {
+                SMO_ACC(1);
+                if (texl[i] != 0)
+                    SMO_ACC(4);
+                else
+                    SMO_ACC(3);
+                if (disc[i] != 0)
+                    SMO_ACC(5);
+            }
+#undef SMO_ACC
+        }
+    cnt[0] += (cnt[0] == 0);
+    total_all += (total_all == 0);
+    out->fraction_matched = (float)cnt[0] / (float)total_all;
+    for (int k = 0; k < 6; k++) {
+        cnt[k] += (cnt[k] == 0);
+        out->rms[k] = sqrtf(ssd[k] / (float)cnt[k]);
+        out->bad[k] = (float)bad[k] / (float)cnt[k];
+    }
+    if (verbose_summary)
+        out->fraction_matched *= 0.1f;               /* :583 */
+    free(trud); free(fwd); free(white); free(occ); free(texl); free(disc); free(sq); free(tmp); free(dd);
+}

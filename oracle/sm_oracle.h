@@ -124,6 +124,25 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
                                    const smo_params *p, int32_t *disp, float *best_cost,
                                    uint8_t *depth, float *fdisp);
 
+/* Evaluator (StcEvaluate.cpp:42-587, ForwardWarp Warp1D.cpp:25-128): occlusion / textureless /
+ * discontinuity masks from the ground truth and the reference image, then RMS and bad-pixel
+ * statistics of fdisp against the truth.  Order of the six entries: all, nonocc, occ, textured,
+ * textureless, discont (the rms_error_* / bad_pixels_* output parameters,
+ * StereoParameters.cpp:217-229).  truth: uchar [h][w] (tight rows); ref: the un-preprocessed
+ * reference image. */
+typedef struct smo_eval {
+    int ignore_border;
+    float bad_thresh, disp_gap;
+    int textureless_width;
+    float textureless_thresh;
+    int discont_width;
+} smo_eval;
+typedef struct smo_eval_out {
+    float rms[6], bad[6], fraction_matched;
+} smo_eval_out;
+void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                  const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out);
+
 /* 1, or the OpenMP thread count of the -fopenmp build (_build/libsm_oracle_omp.so: the same
  * source, rows / column blocks spread over threads, identical results) */
 int smo_threads(void);

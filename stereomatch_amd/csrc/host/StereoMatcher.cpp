@@ -108,6 +108,19 @@ void CStereoMatcher::ComputeCorrespondence()
     if (depth_image.Shape() != shD)
         depth_image.ReAllocate(shD);
     m_float_disparity.ReAllocate(shD);
+    // ground truth in disparity units, zeros when there is none (StereoMatcher.cpp:121-130)
+    m_true_disparity.ReAllocate(shD);
+    const CByteImage &truth_image = m_frame[frame_ref].truth_image;
+    if (truth_image.Shape() == shD) {
+        float t_scale = 1.0f / disp_scale, t_offset = (float)disp_min;
+        bool t_so = (t_scale != 1.0f) || (t_offset != 0.0f);
+        for (int y = 0; y < shD.height; y++) {
+            const uchar *src = truth_image.Row(y);
+            float *dst = m_true_disparity.Row(y);
+            for (int x = 0; x < shD.width; x++)
+                dst[x] = t_so ? src[x] * t_scale + t_offset : (float)src[x];
+        }
+    }
     m_disparity.ReAllocate(shD);
     m_best_cost.ReAllocate(shD);
     if (m_disp_n < 2)
@@ -162,6 +175,7 @@ void CStereoMatcher::ComputeCorrespondence()
             dst[x] = (uchar)val;
         }
     }
+    m_reference = ref;                                        // undo PreProcess for the evaluator (:180)
 }
 
 void CStereoMatcher::PreProcess()
@@ -454,10 +468,4 @@ void CStereoMatcher::Refine()
                        m_row_elems, m_disp_step, d_offset, from_fit ? 1 : 2, (float *)m_dev[B_FDISP]));
     Check(smhip_memcpy2d_d2h(m_ctx, m_float_disparity.Data(), m_float_disparity.RowBytes(), m_dev[B_FDISP],
                              wbytes, wbytes, m_mp.height));
-}
-
-void CStereoMatcher::Evaluate()
-{
-    // The evaluator (StcEvaluate.cpp) is outside the accelerated path; the error statistics keep
-    // their "not computed" value of -1 (ResetOutputParams).
 }

@@ -18,7 +18,7 @@ public:
     CStereoMatcher();
     ~CStereoMatcher();
     void ComputeCorrespondence();
-    void Evaluate();                    // evaluator is outside the hot path: leaves the outputs at -1
+    void Evaluate();                    // StcEvaluate.cpp: masks + RMS / bad-pixel statistics vs the ground truth
     bool UsedFusedPath() const { return m_used_fused; }
     bool allow_fused = true;            // RawCosts+AggrBox+PadCosts+OptWTA in one device call when legal
 
@@ -36,6 +36,11 @@ protected:
     void PadCosts();
     void OptWTA();
     void ComputeEnergy(float &denergy, float &nenergy);
+    void ComputeOcclusions();
+    void ComputeTextureless();
+    void ComputeDisparityDiscont();
+    void ComputeDisparityErrors();
+    void BoxFilterOnDevice(CFloatImage &img, int window, bool average);
 
     void Check(int rc);                 // smhip status -> CError
     void *DeviceBuffer(int slot, size_t bytes);
@@ -56,6 +61,8 @@ protected:
     CIntImage m_disparity;              // winning levels [0 .. m_disp_n-1]
     CFloatImage m_best_cost;            // m_cost at the winner (data term of final_energy)
     CFloatImage m_float_disparity;
+    CFloatImage m_true_disparity;       // ground truth / disp_scale + disp_min (StereoMatcher.cpp:121-130)
+    CByteImage m_occlusion, m_textureless, m_depth_discont;
     size_t m_row_elems = 0;
     enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_MIND, B_CERT, B_FDISP, B_KEYS, B_COUNT };
     void *m_dev[B_COUNT];

@@ -26,6 +26,9 @@ REFERENCE = {
         "SADdiff10": "839f458ab4f316491509f43afd262ae9",
     },
     "final_energy": {"SSD09": 24421442.0},
+    # evaluator output of the SSD09 run with tsukuba/param_in.txt (eval_ignore_border 18, eval_disp_gap 2)
+    "evaluator": {"SSD09": {"rms_error_all": "1.838858", "bad_pixels_all": "0.118238",
+                            "bad_pixels_nonocc": "0.097767"}},
     "source": "BASELINE.md section 2 (reference CPU path, survey-stage probe build)",
 }
 
@@ -35,12 +38,15 @@ def main():
     ref = pnm.read_image(os.path.join(d, "scene1.row3.col3.ppm"))
     mtc = pnm.read_image(os.path.join(d, "scene1.row3.col4.ppm"))
     h, w, b = ref.shape
-    out = {"reference": REFERENCE, "oracle": {"md5": {}, "final_energy": {}}}
+    truth = pnm.read_image(os.path.join(d, "truedisp.row3.col3.pgm"))
+    out = {"reference": REFERENCE, "oracle": {"md5": {}, "final_energy": {}, "evaluator": {}}}
     for name, kw in util.exp_grid() + util.exp4_grid():
         p = O.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
-        _, _, depth, e = O.compute_correspondence(ref, mtc, p)
+        _, _, depth, e, fd = O.compute_correspondence_f(ref, mtc, p)
         out["oracle"]["md5"][name] = util.md5(pnm.pgm_bytes(depth))
         out["oracle"]["final_energy"][name] = e
+        ev = O.evaluate(fd, truth, ref, p, **util.TSUKUBA_EVAL)
+        out["oracle"]["evaluator"][name] = {k: "%f" % v for k, v in ev.items()}   # as results/*.txt prints
     with open(os.path.join(ROOT, "tests", "golden", "tsukuba_anchors.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote %d oracle vectors" % len(out["oracle"]["md5"]))

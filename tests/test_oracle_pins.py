@@ -184,3 +184,20 @@ def test_openmp_build_is_identical(oracle, tsukuba):
     for a, g in zip(want[:3], got[:3]):
         assert a.tobytes() == g.tobytes()
     assert want[3] == got[3] == util.anchors()["reference"]["final_energy"]["SSD09"]
+
+
+def test_evaluator_reproduces_recorded_statistics(oracle, tsukuba):
+    """SSD09 with tsukuba/param_in.txt's eval_ignore_border 18 / eval_disp_gap 2: the three
+    evaluator numbers recorded from the reference (BASELINE.md section 2) come out digit for digit;
+    bad_pixels_nonocc pins the occlusion map (both ForwardWarp passes) as well."""
+    import os
+    import util
+    from stereomatch_amd import pnm
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    truth = pnm.read_image(os.path.join(util.GOLDEN, "tsukuba", "truedisp.row3.col3.pgm"))
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **dict(util.exp_grid())["SSD09"])
+    _, _, _, _, fd = oracle.compute_correspondence_f(ref, mtc, p)
+    ev = oracle.evaluate(fd, truth, ref, p, **util.TSUKUBA_EVAL)
+    for k, v in util.anchors()["reference"]["evaluator"]["SSD09"].items():
+        assert "%f" % ev[k] == v, k

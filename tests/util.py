@@ -9,6 +9,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 # tsukuba/param_in.txt:1-6
 TSUKUBA_SEQ = dict(disp_min=0, disp_max=15, frame_ref=2, frame_match=3, disp_scale=16.0)
+TSUKUBA_EVAL = dict(ignore_border=18, disp_gap=2.0)      # tsukuba/param_in.txt:11-12
 
 
 def anchors():
