@@ -169,6 +169,15 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
                  int w, int h, int n_bands, size_t row_elems, float disp_step, float disp_min,
                  int mode, float *d_fdisp);
 
+/* OptSO (StcOptSO.cpp:30-154): per scan-line, the path through the DSI that minimises data cost +
+ * Potts smoothness, with the horizontal weights of ComputeSmoothnessCosts (StcOptimize.cpp:61-116)
+ * taken from the reference image.  Same winners as the reference's O(D^2) scan (first strict
+ * minimum everywhere, COST_MAX 1e6 as in StereoMatcher.h:57) in O(D) per pixel.  d_best (may be
+ * NULL) receives m_cost at the chosen level.  n_bands (levels) <= 1024. */
+int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands, size_t row_elems,
+                 const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
+                 float opt_grad_thresh, float opt_grad_penalty, int32_t *d_disp, float *d_best);
+
 /* ---- fused path: RawCosts -> AggrBox (1 iteration) -> PadCosts -> OptWTA ----
  * Same results as the four stage calls, without materialising the raw or the aggregated
  * DSI.  Works on the disparity slab [d_first, d_first + d_count) of the D = p->disp_n

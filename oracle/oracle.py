@@ -30,7 +30,7 @@ class Params(C.Structure):
         ("opt_grad_penalty", C.c_float),
         ("disp_step", C.c_float), ("disp_scale", C.c_float),
         ("aggr_subpixel", C.c_int), ("aggr_collapse", C.c_int), ("refine_subpix", C.c_int),
-        ("preproc_blur_iter", C.c_int),
+        ("preproc_blur_iter", C.c_int), ("opt_fn", C.c_int),
     ]
 
 
@@ -68,7 +68,7 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
         diff_lambda=0.15, diff_beta=0.5,
         opt_smoothness=1.0, opt_grad_thresh=5.0, opt_grad_penalty=1.0,
         disp_step=float(step), disp_scale=disp_scale,
-        aggr_subpixel=0, aggr_collapse=0, refine_subpix=0, preproc_blur_iter=0,
+        aggr_subpixel=0, aggr_collapse=0, refine_subpix=0, preproc_blur_iter=0, opt_fn=1,
     )
     for k, v in kw.items():
         if not hasattr(p, k):
@@ -324,3 +324,17 @@ def evaluate(fdisp, truth, ref, p, verbose_summary=True, **kw):
         res["bad_pixels_" + nme] = float(out.bad[i])
     res["fraction_matched"] = float(out.fraction_matched)
     return res
+
+
+def opt_so(cost, ref, p):
+    """OptSO on a DSI [H, W, D]: returns the disparity map."""
+    c = np.ascontiguousarray(cost, np.float32)
+    h, w, d = c.shape
+    ref = _img(ref)
+    disp = np.empty((h, w), np.int32)
+    L = lib()
+    L.smo_opt_so.restype = None
+    L.smo_opt_so.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(C.c_uint8),
+                             C.c_long, C.POINTER(Params), C.POINTER(C.c_int32)]
+    L.smo_opt_so(_fp(c), w, h, d, w * d, _u8(ref), w * ref.shape[2], C.byref(p), _i32(disp))
+    return disp

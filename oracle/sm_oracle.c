@@ -719,7 +719,16 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
         free(mind);
         cost = cost2; mind = mind2; nd = nd2; row_elems = re2; step = 1.0f;
     }
-    smo_wta(cost, w, h, nd, row_elems, d, best_cost);
+    if (p->opt_fn == 3) {                                /* eScanlineOpt, StcOptimize.cpp:229-238 */
+        smo_opt_so(cost, w, h, nd, row_elems, ref, img_row_bytes, p, d);
+        if (best_cost)
+            for (int y = 0; y < h; y++)
+                for (int x = 0; x < w; x++)
+                    best_cost[(size_t)y * w + x] =
+                        cost[(size_t)y * row_elems + (size_t)x * nd + d[(size_t)y * w + x]];
+    } else {
+        smo_wta(cost, w, h, nd, row_elems, d, best_cost);
+    }
     smo_params q = *p;
     q.disp_n = nd;
     float energy = smo_final_energy(cost, row_elems, d, ref, img_row_bytes, &q);
@@ -949,4 +958,64 @@ void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, 
     if (verbose_summary)
         out->fraction_matched *= 0.1f;               /* :583 */
     free(trud); free(fwd); free(white); free(occ); free(texl); free(disc); free(sq); free(tmp); free(dd);
+}
+
+/* ------------------------------------------------------------------------- */
+/* scan-line optimisation: StcOptSO.cpp:30-154 with the horizontal smoothness */
+/* weights of ComputeSmoothnessCosts (StcOptimize.cpp:84-116, band 1)          */
+
+#define SMO_COST_MAX 1000000   /* StereoMatcher.h:57 */
+
+void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
+                long img_row_bytes, const smo_params *p, int32_t *disp)
+{
+    float *sumcost = malloc((size_t)w * nd * sizeof(float));
+    int *trans = malloc((size_t)w * nd * sizeof(int));
+    int nb = p->n_bands;
+    for (int y = 0; y < h; y++) {
+        const float *c = cost + (size_t)y * row_elems;
+        const uint8_t *I = ref + (size_t)y * img_row_bytes;
+        for (int d = 0; d < nd; d++) {               /* :56-60 */
+            trans[d] = -1;
+            sumcost[d] = c[d];
+        }
+        for (int x = 1; x < w; x++) {                /* :71-111 */
+            /* m_smooth(x-1, y, 1): weight between pixels x-1 and x (x-1 < W-1 always holds here) */
+            float smooth = ncost(I + (x - 1) * nb, I + x * nb, nb, p);
+            const float *prev = sumcost + (size_t)(x - 1) * nd;
+            for (int d = 0; d < nd; d++) {
+                float best_cost = SMO_COST_MAX;
+                int best_d1 = -1;
+                for (int d1 = 0; d1 < nd; d1++) {
+                    float cc = prev[d1];
+                    if (d1 != d)
+                        cc += smooth;
+                    if (cc < best_cost) {
+                        best_cost = cc;
+                        best_d1 = d1;
+                    }
+                }
+                sumcost[(size_t)x * nd + d] = best_cost + c[(size_t)x * nd + d];
+                trans[(size_t)x * nd + d] = best_d1;
+            }
+        }
+        int x = w - 1;                               /* :121-133 */
+        float best_cost = SMO_COST_MAX;
+        int best_d = 0;
+        for (int d = 0; d < nd; d++)
+            if (sumcost[(size_t)x * nd + d] < best_cost) {
+                best_cost = sumcost[(size_t)x * nd + d];
+                best_d = d;
+            }
+        int d = best_d;
+        while (x >= 0) {                             /* :144-151 */
+            disp[(size_t)y * w + x] = d;
+            d = trans[(size_t)x * nd + d];
+            if (d < 0)
+                d = 0;   /* only at x == 0 unless a path runs through COST_MAX (the reference asserts) */
+            x--;
+        }
+    }
+    free(trans);
+    free(sumcost);
 }

@@ -53,6 +53,8 @@ typedef struct smo_params {
     int aggr_subpixel, aggr_collapse, refine_subpix;
     /* StereoParameters.h:57-58 */
     int preproc_blur_iter;
+    /* EStereoOptimizeFn, StereoParameters.h:125-136: 1 = WTA (and any other value), 3 = scan-line optimisation */
+    int opt_fn;
 } smo_params;
 
 /* StcRawCosts.cpp:364-367 */
@@ -142,6 +144,11 @@ typedef struct smo_eval_out {
 } smo_eval_out;
 void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
                   const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out);
+
+/* OptSO (StcOptSO.cpp:30-154), the reference's O(D^2)-per-pixel scan, with the horizontal
+ * smoothness weights of StcOptimize.cpp:61-116 computed from `ref` */
+void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
+                long img_row_bytes, const smo_params *p, int32_t *disp);
 
 /* 1, or the OpenMP thread count of the -fopenmp build (_build/libsm_oracle_omp.so: the same
  * source, rows / column blocks spread over threads, identical results) */

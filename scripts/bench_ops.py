@@ -60,6 +60,8 @@ def main():
           lambda: ctx.diffusion_run(cost, cost2, disp_src, W, H, D, re, 0.15, 0.5, 4))
     timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
+    timed("opt_so (scan-line opt.)", 4.0 * N + 2.0 * N,
+          lambda: ctx.opt_so(cost, W, H, D, re, d_ref, W, 1, 20.0, 8.0, 2.0, disp, best))
     print(json.dumps({"shape": [W, H, D], "ops": out}))
 
 

@@ -380,14 +380,31 @@ void CStereoMatcher::OptWTA()
                     (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
 }
 
+void CStereoMatcher::OptSO()
+{
+    // the smoothness weights come from the (pre-processed) reference image on the device
+    Check(smhip_opt_so(m_ctx, (const float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                       (const uint8_t *)m_dev[B_REF], m_reference.RowBytes(), m_mp.n_bands, opt_smoothness,
+                       opt_grad_thresh, opt_grad_penalty, (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
+}
+
 void CStereoMatcher::Optimize()
 {
-    if (opt_fn != eWTA)
-        throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) is on the device path");
-    if (verbose >= eVerboseProgress)
-        fprintf(stderr, "- optimizing: WTA (local minimum)\n");
-    if (!m_used_fused && !m_keys_done)
-        OptWTA();
+    if (opt_fn == eScanlineOpt) {                             // StcOptimize.cpp:229-238, StcOptSO.cpp
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- computing smoothness costs (smoothness = %g, grad_thresh = %g, penalty=%g)\n"
+                            "- optimizing: Scanline Optimization\n",
+                    opt_smoothness, opt_grad_thresh, opt_grad_penalty);
+        OptSO();
+    } else if (opt_fn == eWTA) {
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- optimizing: WTA (local minimum)\n");
+        if (!m_used_fused && !m_keys_done)
+            OptWTA();
+    } else {
+        throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) and 3 (scan-line optimisation) "
+                     "are on the device path");
+    }
     // results to the host (disparity rows are 4*W bytes: already a multiple of 8 or padded here)
     size_t wbytes = (size_t)m_mp.width * 4;
     Check(smhip_memcpy2d_d2h(m_ctx, m_disparity.Data(), m_disparity.RowBytes(), m_dev[B_DISP], wbytes, wbytes,

@@ -35,6 +35,7 @@ protected:
     void AggrCollapse();
     void PadCosts();
     void OptWTA();
+    void OptSO();
     void ComputeEnergy(float &denergy, float &nenergy);
     void ComputeOcclusions();
     void ComputeTextureless();

@@ -8,6 +8,7 @@
 #include "smhip_stage.h"
 #include "smhip_refine.h"
 #include "smhip_multi.h"
+#include "smhip_opt.h"
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -878,6 +879,38 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
     long n_pix = (long)w * h;
     smk::refine_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
         d_cost, d_min, d_disp, w, h, nb, row_elems, disp_step, disp_min, mode, d_fdisp);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t row_elems,
+                 const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
+                 float opt_grad_thresh, float opt_grad_penalty, int32_t *d_disp, float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_ref || !d_disp || img_bands < 1 || img_pitch < (size_t)w * img_bands)
+        return fail(SMHIP_EINVAL, "OptSO: bad image / output arguments");
+    if (nb > 1024)
+        return fail(SMHIP_EINVAL, "OptSO: at most 1024 disparity levels (%d given)", nb);
+    void *smooth = nullptr, *trans = nullptr;
+    rc = ws_get(ctx, WS_BT, (size_t)w * h * sizeof(float), &smooth);
+    if (rc) return rc;
+    rc = ws_get(ctx, WS_TMP, (size_t)w * h * nb * sizeof(int16_t), &trans);
+    if (rc) return rc;
+    dim3 gs((w + 255) / 256, h);
+    smk::smooth_h_kernel<<<gs, 256, 0, ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
+                                                     opt_grad_thresh, opt_grad_penalty, (float *)smooth);
+#define LAUNCH_SO(NV) smk::opt_so_kernel<NV><<<h, 64, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, \
+        (const float *)smooth, (int16_t *)trans, d_disp, d_best)
+    if (nb <= 64)       LAUNCH_SO(1);
+    else if (nb <= 128) LAUNCH_SO(2);
+    else if (nb <= 256) LAUNCH_SO(4);
+    else if (nb <= 512) LAUNCH_SO(8);
+    else                LAUNCH_SO(16);
+#undef LAUNCH_SO
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

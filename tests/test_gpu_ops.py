@@ -360,3 +360,25 @@ def test_preprocess_blur(gpu_ctx, oracle, w, h, b, iters):
     got = gpu_ctx.download(d, (h, pitch), np.uint8)
     assert np.array_equal(got[:, :w * b].reshape(h, w, b), oracle.preprocess_blur(img, iters))
     assert np.all(got[:, w * b:] == 77)
+
+
+@pytest.mark.parametrize("h,w,d,b", [(5, 40, 7, 1), (4, 33, 16, 4), (3, 50, 100, 1), (3, 20, 200, 1),
+                                     (2, 12, 300, 1), (2, 9, 1, 1), (2, 1, 5, 1)])
+@pytest.mark.parametrize("smooth", [(1.0, 5.0, 1.0), (20.0, 8.0, 2.0), (0.0, 5.0, 1.0)])
+def test_opt_so(gpu_ctx, oracle, h, w, d, b, smooth):
+    """smhip_opt_so (O(D) per pixel, wave minima) == the reference's O(D^2) scan restated in the
+    oracle, including ties (integer-valued costs, zero smoothness) -- parity unpinned."""
+    rng = np.random.RandomState(100 + d)
+    c = rng.randint(0, 12, size=(h, w, d)).astype(np.float32)
+    c = np.where(rng.rand(h, w, d) < 0.3, (rng.rand(h, w, d) * 40).astype(np.float32), c)
+    img, _ = synth.noise_pair(w, h, b, seed=200 + d)
+    p = oracle.make_params(w, h, b, disp_max=max(d - 1, 1), opt_smoothness=smooth[0],
+                           opt_grad_thresh=smooth[1], opt_grad_penalty=smooth[2])
+    want = oracle.opt_so(c, img, p)
+    disp, best = gpu_ctx.alloc(h * w * 4), gpu_ctx.alloc(h * w * 4)
+    gpu_ctx.opt_so(up(gpu_ctx, c), w, h, d, w * d, up(gpu_ctx, img), w * b, b, smooth[0], smooth[1],
+                   smooth[2], disp, best)
+    got = gpu_ctx.download(disp, (h, w), np.int32)
+    assert np.array_equal(got, want)
+    gb = gpu_ctx.download(best, (h, w), np.float32)
+    assert np.array_equal(gb, np.take_along_axis(c, want[..., None], axis=2)[..., 0])

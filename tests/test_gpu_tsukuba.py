@@ -122,3 +122,23 @@ def test_preprocess_blur_pipeline(gpu_ctx, tsukuba, oracle):
         util.assert_bit_equal(disp, odisp, "disparity")
         util.assert_bit_equal(best, obest, "best cost")
         assert np.array_equal(depth, odepth)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(opt_fn=3, match_fn=1, aggr_window_size=1, aggr_iter=0, opt_smoothness=20.0, opt_grad_thresh=8.0,
+         opt_grad_penalty=2.0),
+    dict(opt_fn=3, match_fn=1, match_interval=1, aggr_window_size=3, opt_smoothness=5.0),
+])
+def test_scanline_optimisation_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
+    """opt_fn 3 (OptSO) end to end on tsukuba, incl. final_energy's inputs (best cost); oracle
+    only: parity unpinned."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+    odisp, obest, odepth, _ = oracle.compute_correspondence(ref, mtc, p)
+    m, disp, best, depth = run(gpu_ctx, tsukuba, kw)
+    assert not m.used_fused
+    util.assert_bit_equal(disp, odisp, "disparity")
+    util.assert_bit_equal(best, obest, "cost at the chosen level")
+    assert np.array_equal(depth, odepth)
+    assert np.mean(disp != oracle.wta(m.download_cost())[0]) > 0.01      # it is not just WTA
