@@ -904,13 +904,18 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
     smk::smooth_h_kernel<<<gs, 256, 0, ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
                                                      opt_grad_thresh, opt_grad_penalty, (float *)smooth);
 #define LAUNCH_SO(NV) smk::opt_so_kernel<NV><<<h, 64, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, \
-        (const float *)smooth, (int16_t *)trans, d_disp, d_best)
+        (const float *)smooth, (int16_t *)trans, d_disp)
     if (nb <= 64)       LAUNCH_SO(1);
     else if (nb <= 128) LAUNCH_SO(2);
     else if (nb <= 256) LAUNCH_SO(4);
     else if (nb <= 512) LAUNCH_SO(8);
     else                LAUNCH_SO(16);
 #undef LAUNCH_SO
+    if (d_best) {
+        long n_pix = (long)w * h;
+        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+            d_cost, w, h, nb, row_elems, d_disp, d_best);
+    }
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

@@ -50,38 +50,77 @@ __device__ __forceinline__ void wave_first_min(int bo, int bi, int &mo, int &mi)
     mi = wave_min_i32(bo == mo ? bi : 0x7FFFFFFF);
 }
 
+// m_cost at the chosen level (the data term of final_energy reads it): one thread per pixel
+__global__ void gather_best_kernel(const float *__restrict__ cost, int W, int H, int D, size_t row_elems,
+                                   const int32_t *__restrict__ disp, float *__restrict__ best)
+{
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)W * H)
+        return;
+    int y = (int)(p / W), x = (int)(p - (long)y * W);
+    int d = min(max(disp[p], 0), D - 1);
+    best[p] = cost[(size_t)y * row_elems + (size_t)x * D + d];
+}
+
+// One wave per scan-line.  Both sweeps are serial in x, so memory latency is taken out of the
+// chain: DSI columns (forward) and transition columns (backtrack) are fetched a block of B
+// columns ahead -- neither address depends on the running state -- the smoothness weights are
+// held 64 at a time in a lane register, and the backtrack picks trans[x][d] out of the
+// prefetched column with a readlane instead of a dependent load.
 template <int NV>
 __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ cost, int W, int H, int D,
                                                     size_t row_elems, const float *__restrict__ smooth,
-                                                    int16_t *__restrict__ trans, int32_t *__restrict__ disp,
-                                                    float *__restrict__ best)
+                                                    int16_t *__restrict__ trans, int32_t *__restrict__ disp)
 {
+    constexpr int B = (32 / NV) < 8 ? (32 / NV) : 8;          // columns per prefetch block
     const int y = blockIdx.x, lane = threadIdx.x;
     const float *c = cost + (size_t)y * row_elems;
     int16_t *tr = trans + (size_t)y * W * D;
+    const float *sm = smooth + (size_t)y * W;
     const int d0 = lane * NV;
     const float inf = __builtin_inff();
     auto load = [&](int x, float(&v)[NV]) {
 #pragma unroll
         for (int i = 0; i < NV; i++)
-            v[i] = (d0 + i < D) ? c[(size_t)x * D + d0 + i] : inf;
+            v[i] = (x < W && d0 + i < D) ? c[(size_t)x * D + d0 + i] : inf;
     };
-    float sum[NV], nxt[NV];
+    float sum[NV];
     load(0, sum);                                             // :56-60
 #pragma unroll
     for (int i = 0; i < NV; i++)
         if (d0 + i < D)
             tr[d0 + i] = -1;
-    if (W > 1)
-        load(1, nxt);
-    for (int x = 1; x < W; x++) {
-        float cur[NV];
+    // a lane's NV transitions are one aligned vector when D is a multiple of NV
+    typedef short tvec __attribute__((ext_vector_type(NV)));
+    const bool packed = NV > 1 && D % NV == 0;
+    auto tstore = [&](int x, const short(&v)[NV]) {
+        if (packed) {
+            if (d0 < D) {
+                tvec o;
 #pragma unroll
-        for (int i = 0; i < NV; i++)
-            cur[i] = nxt[i];
-        if (x + 1 < W)
-            load(x + 1, nxt);
-        const float s = smooth[(size_t)y * W + x - 1];
+                for (int i = 0; i < NV; i++)
+                    o[i] = v[i];
+                *(tvec *)(tr + (size_t)x * D + d0) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                if (d0 + i < D)
+                    tr[(size_t)x * D + d0 + i] = v[i];
+        }
+    };
+    float cb[2][B][NV];
+#pragma unroll
+    for (int j = 0; j < B; j++)
+        load(1 + j, cb[0][j]);
+    float sv = 0.0f;                                          // smooth[sbase + lane]
+    int sbase = -64;
+    auto step = [&](int x, const float(&cur)[NV]) {
+        if (((x - 1) & ~63) != sbase) {
+            sbase = (x - 1) & ~63;
+            sv = (sbase + lane < W) ? sm[sbase + lane] : 0.0f;
+        }
+        const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sv), (x - 1) & 63));
         // t[d1] = sumcost[x-1][d1] + smooth: overall first minimum, then first minimum of the rest
         int to[NV];
         int bo = 0x7FFFFFFF, bi = 0x7FFFFFFF;
@@ -94,6 +133,7 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
             }
         }
         int m1, i1, m2, i2;
+        short tv[NV];
         wave_first_min(bo, bi, m1, i1);
         bo = 0x7FFFFFFF;
         bi = 0x7FFFFFFF;
@@ -118,10 +158,28 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
                     bd = -1;
                 }
                 sum[i] = bc + cur[i];
-                tr[(size_t)x * D + d] = (int16_t)bd;
+                tv[i] = (short)bd;
+            } else {
+                tv[i] = 0;
             }
         }
-        // (sum[] of a lane is only replaced after every lane has taken part in both minima)
+        tstore(x, tv);
+    };
+    for (int xb = 1; xb < W; xb += 2 * B) {
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            load(xb + B + j, cb[1][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (xb + j < W)
+                step(xb + j, cb[0][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            load(xb + 2 * B + j, cb[0][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (xb + B + j < W)
+                step(xb + B + j, cb[1][j]);
     }
     // cheapest level of the last column (:125-133), first strict minimum below COST_MAX
     int bo = 0x7FFFFFFF, bi = 0x7FFFFFFF;
@@ -137,18 +195,58 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
     wave_first_min(bo, bi, mo, mi);
     if (!(unordered_bits(mo) < SMK_COST_MAX))
         mi = 0;
-    // backtrack (:144-151); the transitions of this row were written by this wave
+    // backtrack (:144-151): the transitions of this row were written by this wave
     __threadfence();
-    if (lane == 0) {
-        int d = mi;
-        for (int x = W - 1; x >= 0; x--) {
-            disp[(size_t)y * W + x] = d;
-            if (best)
-                best[(size_t)y * W + x] = c[(size_t)x * D + d];
-            d = tr[(size_t)x * D + d];
-            if (d < 0)
-                d = 0;      // x == 0, or a path through COST_MAX (the reference asserts there)
+    auto tload = [&](int x, int(&v)[NV]) {
+        if (packed) {
+            tvec o = {};
+            if (x >= 0 && d0 < D)
+                o = *(const tvec *)(tr + (size_t)x * D + d0);
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                v[i] = o[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; i++)
+                v[i] = (x >= 0 && d0 + i < D) ? (int)tr[(size_t)x * D + d0 + i] : 0;
         }
+    };
+    int tb[2][B][NV];
+#pragma unroll
+    for (int j = 0; j < B; j++)
+        tload(W - 1 - j, tb[0][j]);
+    int d = mi;                                               // wave-uniform
+    int dl = 0;                                               // lane (x & 63) keeps the level of pixel x
+    auto back = [&](int x, const int(&t)[NV]) {
+        dl = (lane == (x & 63)) ? d : dl;
+        if ((x & 63) == 0) {
+            if (x + lane < W)
+                disp[(size_t)y * W + x + lane] = dl;
+        }
+        const int src = d / NV, sub = d - src * NV;
+        int nd = 0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            int v = __builtin_amdgcn_readlane(t[i], src);
+            nd = (i == sub) ? v : nd;
+        }
+        d = nd < 0 ? 0 : nd;   // x == 0, or a path through COST_MAX (the reference asserts there)
+    };
+    for (int xb = W - 1; xb >= 0; xb -= 2 * B) {
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            tload(xb - B - j, tb[1][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (xb - j >= 0)
+                back(xb - j, tb[0][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            tload(xb - 2 * B - j, tb[0][j]);
+#pragma unroll
+        for (int j = 0; j < B; j++)
+            if (xb - B - j >= 0)
+                back(xb - B - j, tb[1][j]);
     }
 }
 
