@@ -1,0 +1,70 @@
+"""BASELINE configs 4 and 5 at their full sizes, checked through locality: a band of rows of the
+full-size result must equal, bit for bit, the oracle run on the matching band of the input
+(plus the halo the operator needs), because every operator of the path is local in y apart from
+the box filter's vertical running sum, which starts at the top row.  The oracle cannot run the
+full volumes (17 GB each) in test time; the bands take a few seconds."""
+import numpy as np
+import pytest
+
+import util
+from stereomatch_amd import capi, sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _band(img, y0, y1):
+    return np.ascontiguousarray(img[y0:y1])
+
+
+def test_config4_iterated_aggregation_full_size(gpu_ctx, oracle):
+    """3840x2160, D = 512 (config 4): raw costs, then 10 diffusion iterations / 4 binomial iterations
+    through the multi-iteration passes; rows 1000..1009 against the oracle."""
+    W, H, D = 3840, 2160, 512
+    left, right, _ = synth.scene_pair(W, H, 256)
+    p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    re = W * D
+    a, b = gpu_ctx.alloc(re * H * 4), gpu_ctx.alloc(re * H * 4)
+    y0, y1 = 1000, 1010
+    for name, halo, run, ref_iter in (
+            ("diffusion x10", 10,
+             lambda: gpu_ctx.diffusion_run(a, b, None, W, H, D, re, 0.15, 0.0, 10),
+             lambda c: oracle.diffusion_iter(c, 0.15, 0.0, None)),
+            ("binomial x4", 8,
+             lambda: gpu_ctx.convolve_14641_run(a, b, W, H, D, re, 4),
+             oracle.convolve_14641)):
+        gpu_ctx.raw_costs(d_ref, d_mtc, W, p, a, re)
+        in_b = run()
+        res = b if in_b else a
+        got = np.empty((y1 - y0, W, D), np.float32)
+        gpu_ctx._chk(gpu_ctx.L.smhip_memcpy_d2h(gpu_ctx.h, got.ctypes.data, res.ptr + y0 * re * 4, got.nbytes))
+        b0, b1 = y0 - halo, y1 + halo
+        po = oracle.make_params(W, b1 - b0, 1, disp_max=D - 1, match_fn=1, match_interval=1)
+        want = oracle.raw_costs(_band(left, b0, b1), _band(right, b0, b1), po)
+        n_iter = 10 if halo == 10 else 4
+        for _ in range(n_iter):
+            want = ref_iter(want)
+        util.assert_bit_equal(got, want[halo:halo + (y1 - y0)], name)
+
+
+def test_config5_slab_full_size(gpu_ctx, oracle):
+    """7680x4320, one 128-level slab (levels 512..639 of D = 1024: config 5's per-GPU share) through
+    the fused path; the top 24 rows against the oracle (the vertical running sum starts at row 0)."""
+    W, H, D, d0, n = 7680, 4320, 1024, 512, 128
+    left, right, _ = synth.scene_pair(W, H, 256)
+    p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    keys = gpu_ctx.alloc(W * H * 8)
+    gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, W, p, 9, d0, n, keys)
+    k = gpu_ctx.download(keys, (W, H), np.int64)
+    rows, halo = 24, 4
+    gd, gb = sharding.decode_keys(np.ascontiguousarray(k[:, :rows].T))
+    po = oracle.make_params(W, rows + halo, 1, disp_min=d0, disp_max=d0 + n - 1, match_fn=1,
+                            match_interval=1, aggr_window_size=9)
+    cost = oracle.aggregate(oracle.raw_costs(_band(left, 0, rows + halo), _band(right, 0, rows + halo), po), po)
+    wd, wb = oracle.wta(cost[:rows])
+    assert np.array_equal(gd, wd + d0)
+    util.assert_bit_equal(gb, wb, "slab best cost")
+    # every key of the slab carries a level of the slab
+    lv = (k & 0xFFFFFFFF)
+    assert lv.min() >= d0 and lv.max() < d0 + n
