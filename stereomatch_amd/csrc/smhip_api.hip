@@ -240,6 +240,11 @@ int smhip_shutdown(smhip_ctx *ctx)
     for (int i = 0; i < WS_COUNT; i++)
         if (ctx->ws[i])
             HIP_TRY(hipFree(ctx->ws[i]));
+    if (ctx->ev) {                                   // profiling left open
+        for (int i = 0; i < 3 * ctx->ev_cap; i++)
+            (void)hipEventDestroy(ctx->ev[i]);
+        free(ctx->ev);
+    }
     free(ctx);
     return SMHIP_OK;
 }

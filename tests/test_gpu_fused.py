@@ -187,3 +187,18 @@ def test_exp2_pipeline_fused_equals_staged(gpu_ctx, oracle):
         assert np.array_equal(disp, odisp), fused
         util.assert_bit_equal(best, obest, "best cost")
         assert np.array_equal(depth, odepth)
+
+
+def test_general_shape_narrow_kernels(gpu_ctx, oracle, monkeypatch):
+    """The general-shape fused kernels (narrow slabs of 4-band images whose rows are not 4-byte
+    aligned) stay bit-identical to the oracle; SMHIP_NARROW forces them on an aligned input."""
+    monkeypatch.setenv("SMHIP_NARROW", "1")
+    for w, h, b, D, win in ((61, 23, 1, 16, 9), (40, 17, 4, 7, 5), (33, 12, 1, 32, 4)):
+        left, right = synth.noise_pair(w, h, b, seed=31 + D)
+        kw = dict(disp_max=D - 1, match_fn=1, match_max=3, match_interval=1, aggr_window_size=win)
+        odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
+        m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+        disp, best, _ = m.ComputeCorrespondence(left, right)
+        assert m.used_fused
+        assert np.array_equal(disp, odisp)
+        util.assert_bit_equal(best, obest, "best cost")
