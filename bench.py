@@ -42,6 +42,8 @@ def main():
     ap.add_argument("--window", type=int, default=9)
     ap.add_argument("--bands", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the short config 4 / config 5 measurements reported under 'extra'")
     ap.add_argument("--cpu-rows", type=int, default=1080,
                     help="rows of the workload the CPU baseline is timed on")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
@@ -167,6 +169,8 @@ def main():
             "roofline_fused": fused,
             "kernels": [ka, kb],
         }
+        if world == 1 and not args.no_extra:
+            out["extra"] = extra_configs(np, capi, synth, ctx)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, left, right, args, Dg, win)
             out["cpu_baseline_all_cores"] = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
@@ -176,6 +180,62 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def extra_configs(np, capi, synth, ctx):
+    """BASELINE configs 4 and 5 (per-GPU share), a few repetitions each, reported next to the
+    headline line (not part of `value`): iterated aggregation on a resident 3840x2160x512 DSI and
+    the fused path on a 7680x4320 slab of 128 levels.  frac = SURVEY 8d algorithmic bytes / time /
+    8 TB/s.  Failures are reported, they do not stop the bench."""
+    res = {}
+
+    def timed(fn, reps):
+        fn()
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        ctx.sync()
+        return (time.perf_counter() - t0) / reps
+
+    try:
+        W, H, D = 3840, 2160, 512
+        N = W * H * D
+        left, right, _ = synth.scene_pair(W, H, 256)
+        p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+        d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
+        a, b = ctx.alloc(N * 4), ctx.alloc(N * 4)
+        ctx.raw_costs(d_ref, d_mtc, W, p, a, W * D)
+        for name, iters, fn in (
+                ("binomial_x4", 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
+                ("binomial_x8", 8, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),
+                ("diffusion_x10", 10, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 10)),
+                ("diffusion_x50", 50, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 50))):
+            dt = timed(fn, 2)
+            res["config4_" + name] = {
+                "workload": "3840x2160, D=512, %d iterations on the resident DSI" % iters,
+                "ms": round(dt * 1e3, 3), "ms_per_iteration": round(dt * 1e3 / iters, 3),
+                "G_voxel_iterations_per_s": round(N * iters / dt / 1e9, 1),
+                "frac_of_8N_per_iteration": round(8.0 * N * iters / dt / 1e9 / HBM_PEAK_GBS, 3)}
+        a.free()
+        b.free()
+    except Exception as e:      # noqa: BLE001 - reported, the headline line must still print
+        res["config4_error"] = repr(e)
+    try:
+        W, H, D, n = 7680, 4320, 1024, 128
+        left, right, _ = synth.scene_pair(W, H, 256)
+        p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+        d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
+        keys = ctx.alloc(W * H * 8)
+        dt = timed(lambda: ctx.fused_box_wta_keys(d_ref, d_mtc, W, p, 9, 512, n, keys), 5)
+        nb = 8.0 * W * H * n + 2.0 * W * H + 8.0 * W * H
+        res["config5_slab"] = {
+            "workload": "7680x4320, levels 512..639 of D=1024 (one GPU's share of 8), fused path, keys out",
+            "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(W * H * n / dt / 1e9, 1),
+            "frac_of_8TBs": round(nb / dt / 1e9 / HBM_PEAK_GBS, 3)}
+    except Exception as e:      # noqa: BLE001
+        res["config5_error"] = repr(e)
+    return res
 
 
 def cpu_baseline(np, left, right, args, D, win, openmp=False):
