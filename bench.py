@@ -46,9 +46,17 @@ def main():
                     help="skip the short config 4 / config 5 measurements reported under 'extra'")
     ap.add_argument("--cpu-rows", type=int, default=1080,
                     help="rows of the workload the CPU baseline is timed on")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
+                         "N > 1 code path where the ranks cannot have a GPU each)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")
     args = ap.parse_args()
+    if os.environ.get("BENCH_WATCHDOG"):      # rehearsal aid: dump the stacks and exit instead of hanging
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
     import numpy as np
     import torch
@@ -60,10 +68,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     W, H, b, win = args.width, args.height, args.bands, args.window
     Dg = args.disp_per_gpu
@@ -92,7 +105,11 @@ def main():
     # N > 1: the one exchange step (int64 MIN all-reduce over xGMI) overlaps the next frame
     pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume) if world > 1 else None
 
+    trace = bool(os.environ.get("BENCH_TRACE"))
+
     def step():
+        if trace:
+            print("rank %d step" % rank, file=sys.stderr, flush=True)
         if pipe is not None:
             pipe.submit(0)
         else:
@@ -160,10 +177,12 @@ def main():
                 "workload": "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, "
                             "D=%d (%d levels per GPU%s)" % (
                                 win, win, W, H, b, D, Dg,
-                                ", int64-MIN RCCL all-reduce of keys" if world > 1 else ""),
+                                ", int64-MIN %s all-reduce of keys" % ("RCCL" if args.backend == "nccl" else args.backend)
+                                if world > 1 else ""),
                 "width": W, "height": H, "bands": b, "disp_total": D, "disp_per_gpu": Dg,
                 "window": win, "match_fn": "AD", "match_interval": 1, "match_max": 1000,
-                "parallelism": "disparity slabs x%d" % world},
+                "parallelism": "disparity slabs x%d" % world,
+                "collective_backend": (args.backend if world > 1 else None)},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernel": dominant["kernel"],
             "roofline_fused": fused,
