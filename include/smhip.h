@@ -127,6 +127,16 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst,
                          const float *d_cost0, int w, int h, int n_bands,
                          size_t row_elems, float lambda, float beta);
 
+/* One AggrBayesian iteration (StcDiffusion.cpp:139-308): d_cost = E (in place), d_cost2 = Es
+ * (scratch the size of the DSI), d_cost0 = E0.  iter == 0 first scales E by scale_cost and copies
+ * it to E0 (:182-191).  TOLERANCE MODE -- the only operator here that is not bit-exact: exp and
+ * log come from the device's math library (about 1 ulp from the host's), everything else follows
+ * the reference's order of operations in the reference's precisions. */
+#define SMHIP_BAYES_MAX_LEVELS 128
+int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h,
+                        int n_bands, size_t row_elems, float scale_cost, float mu, float sigmaP,
+                        float epsP, int iter);
+
 /* n_iter iterations of AggrDiffusion / of the binomial filter (the aggr_iter loop of
  * StcAggregate.cpp:265-343) with up to four iterations per pass over the DSI (temporal blocking,
  * csrc/smhip_multi.h); bit-identical to n_iter single calls.  d_a holds the input, d_a and d_b

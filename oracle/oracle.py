@@ -31,6 +31,8 @@ class Params(C.Structure):
         ("disp_step", C.c_float), ("disp_scale", C.c_float),
         ("aggr_subpixel", C.c_int), ("aggr_collapse", C.c_int), ("refine_subpix", C.c_int),
         ("preproc_blur_iter", C.c_int), ("opt_fn", C.c_int),
+        ("diff_scale_cost", C.c_float), ("diff_mu", C.c_float), ("diff_sigmaP", C.c_float),
+        ("diff_epsP", C.c_float),
     ]
 
 
@@ -69,6 +71,7 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
         opt_smoothness=1.0, opt_grad_thresh=5.0, opt_grad_penalty=1.0,
         disp_step=float(step), disp_scale=disp_scale,
         aggr_subpixel=0, aggr_collapse=0, refine_subpix=0, preproc_blur_iter=0, opt_fn=1,
+        diff_scale_cost=0.01, diff_mu=0.5, diff_sigmaP=0.4, diff_epsP=0.01,
     )
     for k, v in kw.items():
         if not hasattr(p, k):
@@ -338,3 +341,18 @@ def opt_so(cost, ref, p):
                              C.c_long, C.POINTER(Params), C.POINTER(C.c_int32)]
     L.smo_opt_so(_fp(c), w, h, d, w * d, _u8(ref), w * ref.shape[2], C.byref(p), _i32(disp))
     return disp
+
+
+def bayesian_iters(cost, n_iter, scale_cost=0.01, mu=0.5, sigmaP=0.4, epsP=0.01):
+    """n_iter iterations of AggrBayesian on a DSI [H, W, D]; returns the energies."""
+    c = np.array(cost, dtype=np.float32, order="C", copy=True)
+    h, w, d = c.shape
+    c2, c0 = np.empty_like(c), np.empty_like(c)
+    L = lib()
+    L.smo_bayesian_iter.restype = None
+    fp = C.POINTER(C.c_float)
+    L.smo_bayesian_iter.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float, C.c_float,
+                                    C.c_float, C.c_float, C.c_int]
+    for it in range(n_iter):
+        L.smo_bayesian_iter(_fp(c), _fp(c2), _fp(c0), w, h, d, w * d, scale_cost, mu, sigmaP, epsP, it)
+    return c

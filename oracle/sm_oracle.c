@@ -446,6 +446,12 @@ void smo_aggregate(float *cost, long row_elems, const smo_params *p)
             memcpy(tmp, cost, bytes);
             smo_diffusion_iter(tmp, cost, cost0, w, h, nb, row_elems, p->diff_lambda, beta);
             break;
+        case SMO_BAYESIAN:                           /* :320-331 */
+            if (!cost0)
+                cost0 = malloc(bytes);
+            smo_bayesian_iter(cost, tmp, cost0, w, h, nb, row_elems, p->diff_scale_cost, p->diff_mu,
+                              p->diff_sigmaP, p->diff_epsP, iter);
+            break;
         default:
             break;
         }
@@ -1018,4 +1024,70 @@ void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const u
     }
     free(trans);
     free(sumcost);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Bayesian diffusion: StcDiffusion.cpp:139-308 (one iteration)               */
+/* g++ resolves exp(float) to the float overload, so the float-argument calls */
+/* (:214, :236) are expf here; log (:253) takes a double.  TOLERANCE MODE:    */
+/* the device's expf / log differ from libm's in the last place.              */
+
+void smo_bayesian_iter(float *cost, float *cost2, float *cost0, int w, int h, int nd, long row_elems,
+                       float scale_cost, float mu, float sigmaP, float epsP, int iter)
+{
+    if (iter == 0) {                                 /* :182-191 */
+        for (int y = 0; y < h; y++)
+            for (long i = 0; i < (long)w * nd; i++) {
+                float *c = cost + (size_t)y * row_elems + i;
+                *c = *c * scale_cost + 0.0f;
+                cost0[(size_t)y * row_elems + i] = *c;
+            }
+    }
+    double *p = malloc((size_t)nd * sizeof(double));
+    double *wt = malloc((size_t)nd * nd * sizeof(double));
+    for (int d = 0; d < nd; d++) {                   /* :209-222 */
+        float s = 0.0;
+        for (int d2 = 0; d2 < nd; d2++) {
+            float diff = (d - d2);
+            s += (wt[(size_t)d * nd + d2] = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP));
+        }
+        for (int d2 = 0; d2 < nd; d2++)
+            wt[(size_t)d * nd + d2] /= s;
+    }
+    for (int y = 0; y < h; y++)                      /* :226-256 */
+        for (int x = 0; x < w; x++) {
+            const float *pE = cost + (size_t)y * row_elems + (size_t)x * nd;
+            float *pEs = cost2 + (size_t)y * row_elems + (size_t)x * nd;
+            double s = 0.;
+            for (int d = 0; d < nd; d++)
+                s += (p[d] = expf(-pE[d]));
+            if (s == 0) {
+                for (int d = 0; d < nd; d++)
+                    p[d] = 1.0 / nd;
+            } else {
+                for (int d = 0; d < nd; d++)
+                    p[d] /= s;
+            }
+            for (int d = 0; d < nd; d++) {
+                double ps = 0;
+                for (int d2 = 0; d2 < nd; d2++)
+                    ps += (wt[(size_t)d * nd + d2] * p[d2]);
+                pEs[d] = -log(1e-16 > ps ? 1e-16 : ps);
+            }
+        }
+    long dx = nd, dy = row_elems;                    /* :261-307 */
+    for (int y = 0; y < h; y++) {
+        float *pE = cost + (size_t)y * row_elems;
+        const float *pEs = cost2 + (size_t)y * row_elems;
+        const float *pE0 = cost0 + (size_t)y * row_elems;
+        for (long x = 0; x < dx * w; x++) {
+            long left = (x - dx >= 0 ? x - dx : x);
+            long right = (x + dx < dx * w ? x + dx : x);
+            long up = (y > 0 ? x - dy : x);
+            long down = (y < h - 1 ? x + dy : x);
+            pE[x] = pE0[x] + mu * (pEs[x] + pEs[left] + pEs[right] + pEs[up] + pEs[down]);
+        }
+    }
+    free(wt);
+    free(p);
 }

@@ -33,7 +33,7 @@ extern "C" {
 
 enum { SMO_AD = 1, SMO_SD = 2 };             /* EStereoMatchFn, StereoParameters.h:33-40 */
 enum { SMO_LINEAR = 1, SMO_CUBIC = 3 };      /* EStereoInterpFn, StereoParameters.h:42-48 */
-enum { SMO_BOX = 1, SMO_BINOMIAL = 2, SMO_DIFFUSION = 3, SMO_MEMBRANE = 4 }; /* :81-97 */
+enum { SMO_BOX = 1, SMO_BINOMIAL = 2, SMO_DIFFUSION = 3, SMO_MEMBRANE = 4, SMO_BAYESIAN = 5 }; /* :81-97 */
 
 typedef struct smo_params {
     /* image geometry */
@@ -55,6 +55,8 @@ typedef struct smo_params {
     int preproc_blur_iter;
     /* EStereoOptimizeFn, StereoParameters.h:125-136: 1 = WTA (and any other value), 3 = scan-line optimisation */
     int opt_fn;
+    /* Bayesian diffusion, StereoParameters.h:112-115 */
+    float diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP;
 } smo_params;
 
 /* StcRawCosts.cpp:364-367 */
@@ -149,6 +151,11 @@ void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, 
  * smoothness weights of StcOptimize.cpp:61-116 computed from `ref` */
 void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
                 long img_row_bytes, const smo_params *p, int32_t *disp);
+
+/* AggrBayesian (StcDiffusion.cpp:139-308), one iteration in place; cost2 = scratch (Es), cost0 =
+ * E0 (written when iter == 0).  Tolerance mode: see the note in sm_oracle.c. */
+void smo_bayesian_iter(float *cost, float *cost2, float *cost0, int w, int h, int nd, long row_elems,
+                       float scale_cost, float mu, float sigmaP, float epsP, int iter);
 
 /* 1, or the OpenMP thread count of the -fopenmp build (_build/libsm_oracle_omp.so: the same
  * source, rows / column blocks spread over threads, identical results) */

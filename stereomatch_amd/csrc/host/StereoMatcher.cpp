@@ -297,8 +297,19 @@ void CStereoMatcher::Aggregate()
                                       &in_b));
         }
         break;
-    case eBayesian:
-        throw CError("CStereoMatcher::Aggregate(): Bayesian diffusion is not on the device path");
+    case eBayesian:                                           // StcAggregate.cpp:320-330, tolerance mode
+        if (verbose >= eVerboseProgress && aggr_iter > 0)
+            fprintf(stderr, "- aggregating: Bayesian model, scale=%g, mu=%g, sigmaP=%g, epsP=%g\n",
+                    diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP);
+        if (aggr_iter > 0) {
+            DeviceBuffer(B_COST2, bytes);
+            DeviceBuffer(B_COST0, bytes);
+        }
+        for (int iter = 0; iter < aggr_iter; iter++)
+            Check(smhip_bayesian_iter(m_ctx, (float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                                      (float *)m_dev[B_COST0], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                                      diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP, iter));
+        break;
     default:
         throw CError("CStereoMatcher::Aggregate(): unknown aggregation function");
     }

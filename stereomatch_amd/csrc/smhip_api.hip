@@ -9,7 +9,9 @@
 #include "smhip_refine.h"
 #include "smhip_multi.h"
 #include "smhip_opt.h"
+#include "smhip_bayes.h"
 
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -47,6 +49,9 @@ struct smhip_ctx {
     size_t ws_bytes[WS_COUNT];
     hipEvent_t *ev;      // 3 events per profiled fused call
     int ev_cap, ev_used; // in calls
+    double *bayes_w, *bayes_wh;          // AggrBayesian weights: device copy, host copy
+    int bayes_n, bayes_band;             // levels they were computed for (0: none), half band width
+    float bayes_sigma, bayes_eps;
 };
 
 namespace {
@@ -240,6 +245,9 @@ int smhip_shutdown(smhip_ctx *ctx)
     for (int i = 0; i < WS_COUNT; i++)
         if (ctx->ws[i])
             HIP_TRY(hipFree(ctx->ws[i]));
+    if (ctx->bayes_w)
+        HIP_TRY(hipFree(ctx->bayes_w));
+    free(ctx->bayes_wh);
     if (ctx->ev) {                                   // profiling left open
         for (int i = 0; i < 3 * ctx->ev_cap; i++)
             (void)hipEventDestroy(ctx->ev[i]);
@@ -921,6 +929,82 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
         smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
             d_cost, w, h, nb, row_elems, d_disp, d_best);
     }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h, int nb,
+                        size_t row_elems, float scale_cost, float mu, float sigmaP, float epsP, int iter)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_cost2 || !d_cost0 || d_cost2 == d_cost || d_cost0 == d_cost || d_cost0 == d_cost2)
+        return fail(SMHIP_EINVAL, "Bayesian diffusion needs three distinct volumes (E, Es, E0)");
+    if (nb > SMHIP_BAYES_MAX_LEVELS)                 // the reference asserts m_disp_n < 100 (:200-202)
+        return fail(SMHIP_EINVAL, "Bayesian diffusion: at most %d disparity levels (%d given)",
+                    SMHIP_BAYES_MAX_LEVELS, nb);
+    if (h > 65535)
+        return fail(SMHIP_EINVAL, "Bayesian diffusion: at most 65535 rows");
+    if (iter < 0)
+        return fail(SMHIP_EINVAL, "negative iteration index");
+    static_assert(SMHIP_BAYES_MAX_LEVELS == smk::BAYES_MAXD, "header and kernel limits differ");
+    const int DP = nb <= 64 ? 64 : 128;
+    const size_t band_cap = (size_t)(2 * SMHIP_BAYES_MAX_LEVELS - 1) * SMHIP_BAYES_MAX_LEVELS;
+    if (ctx->bayes_n != nb || ctx->bayes_sigma != sigmaP || ctx->bayes_eps != epsP) {
+        // w(d, d') = rhoP(d - d') / row sum, on the host as the reference computes it (:209-222),
+        // then the band (w - e_d) and e_d = epsP / s_d the kernel sums (see smhip_bayes.h)
+        const size_t cap = (band_cap + SMHIP_BAYES_MAX_LEVELS) * sizeof(double);
+        if (!ctx->bayes_wh && !(ctx->bayes_wh = (double *)malloc(cap)))
+            return fail(SMHIP_ENOMEM, "out of host memory");
+        if (!ctx->bayes_w)
+            HIP_TRY(hipMalloc((void **)&ctx->bayes_w, cap));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // an earlier iteration may still read the old ones
+        int B = 0;
+        for (int d = 1; d < nb; d++) {
+            float diff = d;
+            float r = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP);
+            if (!(r == epsP))
+                B = d;
+        }
+        double *band = ctx->bayes_wh, *ed = band + band_cap, row[SMHIP_BAYES_MAX_LEVELS];
+        memset(band, 0, cap);
+        for (int d = 0; d < nb; d++) {
+            float s = 0.0;
+            for (int d2 = 0; d2 < nb; d2++) {
+                float diff = (d - d2);
+                s += (row[d2] = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP));
+            }
+            for (int d2 = 0; d2 < nb; d2++)
+                row[d2] /= s;
+            double e = B < nb - 1 ? (double)epsP : 0.0;   // the full product has no constant part
+            e /= s;
+            ed[d] = e;
+            for (int k = -B; k <= B; k++)
+                if (d + k >= 0 && d + k < nb)
+                    band[(size_t)(k + B) * DP + d] = row[d + k] - e;
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->bayes_w, band, cap, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->bayes_n = nb;
+        ctx->bayes_sigma = sigmaP;
+        ctx->bayes_eps = epsP;
+        ctx->bayes_band = B;
+    }
+    long n_pix = (long)w * h;
+    unsigned blocks = (unsigned)((n_pix + 3) / 4 < 4096 ? (n_pix + 3) / 4 : 4096);
+    float *e0 = iter == 0 ? d_cost0 : nullptr;
+    if (DP == 64)
+        smk::bayes_smooth_kernel<1><<<blocks, 256, 0, ctx->stream>>>(d_cost, d_cost2, e0, scale_cost, ctx->bayes_w,
+                                                                    ctx->bayes_w + band_cap, ctx->bayes_band, w, h,
+                                                                    nb, row_elems);
+    else
+        smk::bayes_smooth_kernel<2><<<blocks, 256, 0, ctx->stream>>>(d_cost, d_cost2, e0, scale_cost, ctx->bayes_w,
+                                                                    ctx->bayes_w + band_cap, ctx->bayes_band, w, h,
+                                                                    nb, row_elems);
+    dim3 ge((w * nb + 255) / 256, h);
+    smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(d_cost, d_cost2, d_cost0, w, nb, h, row_elems, mu);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

@@ -1,0 +1,112 @@
+// smhip_bayes.h -- one iteration of Bayesian diffusion (AggrBayesian, StcDiffusion.cpp:139-308).
+//
+//   1. P(d)  = exp(-E(d)) / sum            per pixel           (float exp, double accumulation)
+//   2. Ps(d) = sum_d2 w[d][d2] * P(d2)     D x D weights       (double)
+//   3. Es(d) = -log(max(1e-16, Ps(d)))                          (double log, stored as float)
+//   4. E     = E0 + mu * (Es + left + right + up + down)        (float, 5-point, replicate border)
+//
+// TOLERANCE MODE: steps 1 and 3 call the device's expf / log, which differ from the host libm
+// the reference uses in the last place (and the host's own result depends on which libm variant
+// the CPU selects), so this operator is not bit-exact -- every other operator of the library is.
+//
+// Step 2 is a D x D product per pixel, but the matrix is a band plus a constant: beyond
+// |d - d'| = B the Gaussian term of rhoP underflows and w(d, d') is exactly epsP / s_d =: e_d.
+// With sum_d' P(d') = 1:   Ps(d) = sum_{|k| <= B} (w(d, d+k) - e_d) * P(d+k) + e_d,
+// 2B+1 terms instead of D (B = 5 for the reference's sigmaP 0.4; B = D-1, i.e. the full product,
+// when there is no such cut-off).  The host computes w as the reference does (:209-222), finds B
+// and uploads the band; the device sums it with FMAs in double.  One wave per pixel, lane l holds
+// levels l and l + 64 (D <= 128; the reference stops at 99, MAXDISP :200-202); the normalised
+// probabilities go through a wave-private, zero-padded LDS line so lane d reads P(d+k).
+#pragma once
+
+#include "smhip_kernels.h"
+
+namespace smk {
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1)
+        v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+constexpr int BAYES_MAXD = 128;          // == SMHIP_BAYES_MAX_LEVELS
+constexpr int BAYES_LINE = 3 * BAYES_MAXD;
+
+// steps 1-3: E -> Es.  wb = band [(2B+1)][64*SLOTS] of (w - e_d), zero outside the matrix;
+// ed = e_d per level.  E0 != nullptr (first iteration): E *= scale first, and E0 = E (:182-191).
+template <int SLOTS>
+__global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E, float *__restrict__ Es,
+                                                           float *__restrict__ E0, float scale,
+                                                           const double *__restrict__ wb,
+                                                           const double *__restrict__ ed, int B, int W, int H,
+                                                           int D, size_t row_elems)
+{
+    constexpr int DP = 64 * SLOTS;
+    __shared__ double line[4][BAYES_LINE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *pl = line[wave];
+    for (int i = lane; i < BAYES_LINE; i += 64)
+        pl[i] = 0.0;
+    const int dA = lane, dB = lane + 64;
+    const bool inA = dA < D, inB = SLOTS > 1 && dB < D;
+    const double edA = inA ? ed[dA] : 0.0, edB = inB ? ed[dB] : 0.0;
+    const long n_pix = (long)W * H, n_waves = (long)gridDim.x * 4;
+    for (long pix = (long)blockIdx.x * 4 + wave; pix < n_pix; pix += n_waves) {   // wave-uniform
+        const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+        const size_t o = (size_t)y * row_elems + (size_t)x * D;
+        float eA = inA ? E[o + dA] : 0.0f, eB = inB ? E[o + dB] : 0.0f;
+        if (E0) {
+            eA = eA * scale + 0.0f;
+            eB = eB * scale + 0.0f;
+            if (inA) E[o + dA] = E0[o + dA] = eA;
+            if (inB) E[o + dB] = E0[o + dB] = eB;
+        }
+        double pA = inA ? (double)expf(-eA) : 0.0;          // :236
+        double pB = inB ? (double)expf(-eB) : 0.0;
+        const double s = wave_sum_f64(pA + pB);
+        if (s == 0) {                                       // :238-241
+            pA = inA ? 1.0 / D : 0.0;
+            pB = inB ? 1.0 / D : 0.0;
+        } else {
+            pA /= s;
+            pB /= s;
+        }
+        __builtin_amdgcn_wave_barrier();                    // the previous pixel's reads are done
+        if (inA) pl[BAYES_MAXD + dA] = pA;
+        if (inB) pl[BAYES_MAXD + dB] = pB;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double psA = edA, psB = edB;                        // :247-250, band + constant
+        const double *wk = wb;
+        for (int k = -B; k <= B; k++, wk += DP) {
+            psA = fma(wk[dA], pl[BAYES_MAXD + dA + k], psA);
+            if (SLOTS > 1)
+                psB = fma(wk[dB], pl[BAYES_MAXD + dB + k], psB);
+        }
+        if (inA)
+            Es[o + dA] = (float)(-log(1e-16 > psA ? 1e-16 : psA));   // :253
+        if (inB)
+            Es[o + dB] = (float)(-log(1e-16 > psB ? 1e-16 : psB));
+    }
+}
+
+// step 4 (:261-307): E = E0 + mu * ((((Es + left) + right) + up) + down), missing neighbour = centre
+__global__ void bayes_update_kernel(float *__restrict__ E, const float *__restrict__ Es,
+                                    const float *__restrict__ E0, int W, int D, int H, size_t row_elems, float mu)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int y = blockIdx.y;
+    if (i >= W * D)
+        return;
+    const float *s = Es + (size_t)y * row_elems + i;
+    long lf = (i - D >= 0) ? -(long)D : 0;
+    long rt = (i + D < W * D) ? (long)D : 0;
+    long up = (y > 0) ? -(long)row_elems : 0;
+    long dn = (y < H - 1) ? (long)row_elems : 0;
+    size_t o = (size_t)y * row_elems + i;
+    E[o] = E0[o] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
+}
+
+}  // namespace smk

@@ -46,6 +46,8 @@ class StereoParameters:
         self.aggr_fn, self.aggr_window_size, self.aggr_iter = eBox, 7, 1
         self.aggr_minfilter, self.aggr_subpixel, self.aggr_collapse = 0, 0, 0
         self.diff_lambda, self.diff_beta = 0.15, 0.5
+        self.diff_scale_cost, self.diff_mu = 0.01, 0.5       # StereoParameters.cpp:80-83
+        self.diff_sigmaP, self.diff_epsP = 0.4, 0.01
         self.opt_fn = eWTA
         self.opt_smoothness, self.opt_grad_thresh, self.opt_grad_penalty = 1.0, 5.0, 1.0
         self.refine_subpix = 0
@@ -198,6 +200,13 @@ class StereoMatcher(StereoParameters):
                 if in_b:
                     self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
                     self.d_cost = other
+        elif self.aggr_fn == eBayesian:                                   # :320-330, tolerance mode
+            if self.aggr_iter > 0:
+                es = self._buf("cost2", nbytes)
+                e0 = self._buf("cost0", nbytes)
+                for it in range(self.aggr_iter):
+                    c.bayesian_iter(self.d_cost, es, e0, w, h, nb, re, self.diff_scale_cost, self.diff_mu,
+                                    self.diff_sigmaP, self.diff_epsP, it)
         else:
             raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
         if self.aggr_minfilter > 1 and self._min_wta_fusable():          # :351-365 + OptWTA, no DSI write

@@ -382,3 +382,53 @@ def test_opt_so(gpu_ctx, oracle, h, w, d, b, smooth):
     assert np.array_equal(got, want)
     gb = gpu_ctx.download(best, (h, w), np.float32)
     assert np.array_equal(gb, np.take_along_axis(c, want[..., None], axis=2)[..., 0])
+
+
+# AggrBayesian is the one operator in TOLERANCE MODE: exp / log come from the device's math
+# library, about 1 ulp from the host libm the oracle (and the reference) calls, and an energy is
+# -log of a sum of such values.  Stated tolerance: |E_gpu - E_oracle| <= BAYES_RTOL * max(1, |E|)
+# per iteration chain of up to 5 iterations.
+BAYES_RTOL = 1e-5
+
+
+@pytest.mark.parametrize("h,w,d,pad", [(6, 20, 7, 0), (5, 9, 64, 3), (4, 11, 99, 0), (3, 7, 128, 0),
+                                       (3, 13, 65, 1), (1, 9, 16, 0), (7, 1, 5, 0), (2, 2, 2, 0)])
+@pytest.mark.parametrize("n_iter", [1, 5])
+@pytest.mark.parametrize("prior", [(0.4, 0.01), (3.0, 0.05), (1.5, 0.0), (30.0, 0.01)])
+def test_bayesian_iter(gpu_ctx, oracle, h, w, d, pad, n_iter, prior):
+    """smhip_bayesian_iter vs the oracle's restatement of StcDiffusion.cpp:139-308 -- parity
+    unpinned (the reference holds no fixture for aggr_fn 5), tolerance stated above."""
+    c = util.rand_dsi(h, w, d, 60 + d, "float") * np.float32(0.4)      # energies 0 .. 6.4 after scaling
+    c[::2, ::3, ::4] *= np.float32(40.0)                               # and some whose exp underflows
+    sp, ep = prior        # narrow band + constant (the reference's default), wide bands, full matrix
+    want = oracle.bayesian_iters(c, n_iter, 0.016, 0.5, sp, ep)
+    re = w * d + pad
+    es, e0 = gpu_ctx.alloc(h * re * 4), gpu_ctx.alloc(h * re * 4)
+    def run(b, W, H, D, r):
+        for it in range(n_iter):
+            gpu_ctx.bayesian_iter(b, es, e0, W, H, D, r, 0.016, 0.5, sp, ep, it)
+    got = run_inplace(gpu_ctx, c, run, pad)
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(1.0, np.abs(want))
+    assert np.isfinite(got).all()
+    assert err.max() <= BAYES_RTOL, "max relative deviation %.3g" % err.max()
+    same = np.mean(np.argmin(got, axis=2) == np.argmin(want, axis=2))
+    assert same >= 0.99, "winners agree on %.4f of the pixels" % same
+
+
+def test_bayesian_underflow_and_limits(gpu_ctx, oracle):
+    """Energies so large that every exp underflows take the uniform branch (:238-241); more than
+    SMHIP_BAYES_MAX_LEVELS levels and aliased volumes are refused."""
+    h, w, d = 3, 5, 9
+    c = np.full((h, w, d), 1.0e4, np.float32) + util.rand_dsi(h, w, d, 3, "float")
+    want = oracle.bayesian_iters(c, 2, 1.0, 0.5, 0.4, 0.01)
+    es, e0 = gpu_ctx.alloc(c.nbytes), gpu_ctx.alloc(c.nbytes)
+    def run(b, W, H, D, r):
+        for it in range(2):
+            gpu_ctx.bayesian_iter(b, es, e0, W, H, D, r, 1.0, 0.5, 0.4, 0.01, it)
+    got = run_inplace(gpu_ctx, c, run)
+    assert np.abs(got - want).max() <= BAYES_RTOL * np.abs(want).max()
+    big = gpu_ctx.alloc(2 * 2 * 129 * 4)
+    with pytest.raises(capi.SmhipError, match="at most 128"):
+        gpu_ctx.bayesian_iter(big, es, e0, 2, 2, 129, 2 * 129, 1.0, 0.5, 0.4, 0.01, 0)
+    with pytest.raises(capi.SmhipError, match="distinct"):
+        gpu_ctx.bayesian_iter(es, es, e0, w, h, d, w * d, 1.0, 0.5, 0.4, 0.01, 0)

@@ -142,3 +142,25 @@ def test_scanline_optimisation_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
     util.assert_bit_equal(best, obest, "cost at the chosen level")
     assert np.array_equal(depth, odepth)
     assert np.mean(disp != oracle.wta(m.download_cost())[0]) > 0.01      # it is not just WTA
+
+
+def test_bayesian_diffusion_vs_oracle(gpu_ctx, tsukuba, oracle):
+    """aggr_fn 5 (AggrBayesian) with the settings StcDiffusion.cpp:173-178 suggests, end to end on
+    tsukuba.  TOLERANCE MODE (device exp / log, see tests/test_gpu_ops.py BAYES_RTOL): energies
+    within 1e-4 relative after 10 iterations, winners equal on >= 99.5 % of the pixels.  Oracle
+    only: parity unpinned."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    kw = dict(aggr_fn=5, aggr_iter=10, match_fn=2, match_max=12, diff_scale_cost=0.016, diff_mu=0.5,
+              diff_sigmaP=0.4, diff_epsP=0.01)
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+    ocost = oracle.aggregate(oracle.raw_costs(ref, mtc, p), p)
+    odisp, _, _, _ = oracle.compute_correspondence(ref, mtc, p)
+    m, disp, best, depth = run(gpu_ctx, tsukuba, kw)
+    assert not m.used_fused
+    cost = m.download_cost()
+    err = np.abs(cost.astype(np.float64) - ocost) / np.maximum(1.0, np.abs(ocost))
+    assert err.max() <= 1e-4, "max relative deviation %.3g" % err.max()
+    agree = np.mean(disp == odisp)
+    assert agree >= 0.995, "winners agree on %.5f of the pixels" % agree
+    assert np.mean(disp != oracle.wta(oracle.raw_costs(ref, mtc, p))[0]) > 0.05   # it did aggregate
