@@ -188,6 +188,16 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
                  const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
                  float opt_grad_thresh, float opt_grad_penalty, int32_t *d_disp, float *d_best);
 
+/* OptDP (StcOptDP.cpp:110-332): per scan-line dynamic programming over matched / left-occluded /
+ * right-occluded cells with occlusion cost opt_occlusion_cost and the horizontal smoothness weights
+ * of ComputeSmoothnessCosts on the occluded -> matched transitions; occluded pixels are then filled
+ * from the left (:78-107).  Same float operations in the same order as the reference (bit-exact).
+ * d_best (may be NULL) receives m_cost at the chosen level.  n_bands (levels) <= 1024. */
+int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands, size_t row_elems,
+                 const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
+                 float opt_grad_thresh, float opt_grad_penalty, int opt_occlusion_cost,
+                 int32_t *d_disp, float *d_best);
+
 /* ---- fused path: RawCosts -> AggrBox (1 iteration) -> PadCosts -> OptWTA ----
  * Same results as the four stage calls, without materialising the raw or the aggregated
  * DSI.  Works on the disparity slab [d_first, d_first + d_count) of the D = p->disp_n

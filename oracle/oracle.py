@@ -32,7 +32,7 @@ class Params(C.Structure):
         ("aggr_subpixel", C.c_int), ("aggr_collapse", C.c_int), ("refine_subpix", C.c_int),
         ("preproc_blur_iter", C.c_int), ("opt_fn", C.c_int),
         ("diff_scale_cost", C.c_float), ("diff_mu", C.c_float), ("diff_sigmaP", C.c_float),
-        ("diff_epsP", C.c_float),
+        ("diff_epsP", C.c_float), ("opt_occlusion_cost", C.c_int),
     ]
 
 
@@ -72,6 +72,7 @@ def make_params(width, height, n_bands, disp_min=0, disp_max=7, disp_step=1.0,
         disp_step=float(step), disp_scale=disp_scale,
         aggr_subpixel=0, aggr_collapse=0, refine_subpix=0, preproc_blur_iter=0, opt_fn=1,
         diff_scale_cost=0.01, diff_mu=0.5, diff_sigmaP=0.4, diff_epsP=0.01,
+        opt_occlusion_cost=20,
     )
     for k, v in kw.items():
         if not hasattr(p, k):
@@ -340,6 +341,20 @@ def opt_so(cost, ref, p):
     L.smo_opt_so.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(C.c_uint8),
                              C.c_long, C.POINTER(Params), C.POINTER(C.c_int32)]
     L.smo_opt_so(_fp(c), w, h, d, w * d, _u8(ref), w * ref.shape[2], C.byref(p), _i32(disp))
+    return disp
+
+
+def opt_dp(cost, ref, p):
+    """OptDP (StcOptDP.cpp:110-332) on a DSI [H, W, D] with the reference image's gradients."""
+    c = np.ascontiguousarray(cost, np.float32)
+    ref = _img(ref)
+    h, w, d = c.shape
+    disp = np.empty((h, w), np.int32)
+    L = lib()
+    L.smo_opt_dp.restype = None
+    L.smo_opt_dp.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_long, C.POINTER(C.c_uint8),
+                             C.c_long, C.POINTER(Params), C.POINTER(C.c_int32)]
+    L.smo_opt_dp(_fp(c), w, h, d, w * d, _u8(ref), w * ref.shape[2], C.byref(p), _i32(disp))
     return disp
 
 

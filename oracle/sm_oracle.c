@@ -725,8 +725,11 @@ float smo_compute_correspondence_f(const uint8_t *ref, const uint8_t *mtc, long 
         free(mind);
         cost = cost2; mind = mind2; nd = nd2; row_elems = re2; step = 1.0f;
     }
-    if (p->opt_fn == 3) {                                /* eScanlineOpt, StcOptimize.cpp:229-238 */
-        smo_opt_so(cost, w, h, nd, row_elems, ref, img_row_bytes, p, d);
+    if (p->opt_fn == 3 || p->opt_fn == 2) {              /* eScanlineOpt / eDynamicProg, StcOptimize.cpp:217-238 */
+        if (p->opt_fn == 3)
+            smo_opt_so(cost, w, h, nd, row_elems, ref, img_row_bytes, p, d);
+        else
+            smo_opt_dp(cost, w, h, nd, row_elems, ref, img_row_bytes, p, d);
         if (best_cost)
             for (int y = 0; y < h; y++)
                 for (int x = 0; x < w; x++)
@@ -1024,6 +1027,94 @@ void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const u
     }
     free(trans);
     free(sumcost);
+}
+
+/* ------------------------------------------------------------------------- */
+/* dynamic programming: StcOptDP.cpp:110-332.  Per scan-line, every cell (x, d) */
+/* has the states M (matched), L, R (occluded) with cumulative costs; seven     */
+/* transitions (:137-149), candidates tried in the order t = 0..6 with a strict */
+/* '<' against the state's current value, which starts at COST_MAX (:188-229).  */
+/* Predecessors: t 0,1,6 = (x-1, d), t 2,3 = (x-1, d-1), t 4,5 = (x, d+1) --    */
+/* the column is filled from d = D-1 down, so the 'up' cell is already final.   */
+
+void smo_opt_dp(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
+                long img_row_bytes, const smo_params *p, int32_t *disp)
+{
+    static const int cstate[7] = {0, 1, 1, 0, 2, 2, 0};     /* :137-138 */
+    static const int pstate[7] = {0, 0, 1, 1, 0, 2, 2};
+    static const int dx[7] = {-1, -1, -1, -1, 0, 0, -1};    /* :141-145 as (x, d) steps */
+    static const int dd[7] = {0, 0, -1, -1, 1, 1, 0};
+    const int occ = -9999;                                  /* :119 */
+    const float ocL = (float)p->opt_occlusion_cost, ocR = ocL;   /* :116-117 */
+    int nb = p->n_bands;
+    float *sum = malloc((size_t)w * nd * 3 * sizeof(float));
+    signed char *tr = malloc((size_t)w * nd * 3);
+    for (int y = 0; y < h; y++) {
+        const float *c = cost + (size_t)y * row_elems;
+        const uint8_t *I = ref + (size_t)y * img_row_bytes;
+        int32_t *out = disp + (size_t)y * w;
+        for (int d = 0; d < nd; d++) {                      /* :162-170 */
+            float *s = sum + (size_t)d * 3;
+            signed char *t = tr + (size_t)d * 3;
+            t[0] = 0; t[1] = -1; t[2] = -1;
+            s[0] = c[d]; s[1] = SMO_COST_MAX; s[2] = SMO_COST_MAX;
+        }
+        for (int x = 1; x < w; x++) {                       /* :179-236 */
+            float smooth = ncost(I + (x - 1) * nb, I + x * nb, nb, p);   /* m_smooth(x-1, y, 1), :174 */
+            const float *cx = c + (size_t)x * nd;
+            for (int d = nd - 1; d >= 0; d--) {
+                float *s = sum + ((size_t)x * nd + d) * 3;
+                signed char *t = tr + ((size_t)x * nd + d) * 3;
+                s[0] = s[1] = s[2] = SMO_COST_MAX;
+                t[0] = t[1] = t[2] = -1;
+                for (int k = 0; k < 7; k++) {
+                    if ((d == 0 && dd[k] < 0) || (d == nd - 1 && dd[k] > 0))   /* :148-149, :200-203 */
+                        continue;
+                    int cs = cstate[k];
+                    float cinc = cs == 1 ? ocL : (cs == 2 ? ocR : cx[d]);
+                    if (k == 3 || k == 6)
+                        cinc += smooth;
+                    float cand = sum[((size_t)(x + dx[k]) * nd + (d + dd[k])) * 3 + pstate[k]] + cinc;
+                    if (cand < s[cs]) {
+                        s[cs] = cand;
+                        t[cs] = (signed char)k;
+                    }
+                }
+            }
+        }
+        for (int x = 0; x < w; x++)
+            out[x] = occ;                                   /* (only seen if the walk below stops early) */
+        int x = w - 1, d = 0, st = 0;                       /* :256-274: matched cells of the last column */
+        float best = SMO_COST_MAX;
+        for (int k = 0; k < nd; k++)
+            if (sum[((size_t)x * nd + k) * 3] < best) {
+                best = sum[((size_t)x * nd + k) * 3];
+                d = k;
+            }
+        while (x >= 0) {                                    /* :292-322 */
+            int k = tr[((size_t)x * nd + d) * 3 + st];
+            if (k < 0)
+                break;   /* a path through COST_MAX: the reference indexes cstate[-1] here */
+            out[x] = cstate[k] == 0 ? d : occ;
+            st = pstate[k];
+            x += dx[k];
+            d += dd[k];
+        }
+        /* fill_occluded_pixels (:78-107), left to right: holes take the last matched value to
+         * their left, leading holes the first matched value of the line */
+        for (x = 0; x < w; x++)
+            if (out[x] != occ)
+                break;
+        int oldd = x < w ? out[x] : 0;                      /* (the last pixel is always matched) */
+        for (x = 0; x < w; x++) {
+            if (out[x] == occ)
+                out[x] = oldd;
+            else
+                oldd = out[x];
+        }
+    }
+    free(tr);
+    free(sum);
 }
 
 /* ------------------------------------------------------------------------- */

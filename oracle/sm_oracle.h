@@ -57,6 +57,7 @@ typedef struct smo_params {
     int opt_fn;
     /* Bayesian diffusion, StereoParameters.h:112-115 */
     float diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP;
+    int opt_occlusion_cost;              /* StereoParameters.cpp:90 (20) */
 } smo_params;
 
 /* StcRawCosts.cpp:364-367 */
@@ -149,6 +150,8 @@ void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, 
 
 /* OptSO (StcOptSO.cpp:30-154), the reference's O(D^2)-per-pixel scan, with the horizontal
  * smoothness weights of StcOptimize.cpp:61-116 computed from `ref` */
+void smo_opt_dp(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
+                long img_row_bytes, const smo_params *p, int32_t *disp);
 void smo_opt_so(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,
                 long img_row_bytes, const smo_params *p, int32_t *disp);
 

@@ -24,7 +24,7 @@ SYMBOLS = [
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
-    "smhip_opt_so", "smhip_bayesian_iter",
+    "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     L.smhip_min_pad_wta_keys.argtypes = [vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_preprocess_blur.argtypes = [vp, vp, sz, ci, ci, ci, ci]
     L.smhip_opt_so.argtypes = [vp, vp, ci, ci, ci, sz, vp, sz, ci, cf, cf, cf, vp, vp]
+    L.smhip_opt_dp.argtypes = [vp, vp, ci, ci, ci, sz, vp, sz, ci, cf, cf, cf, ci, vp, vp]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
@@ -291,6 +292,12 @@ class Context:
         self._chk(self.L.smhip_opt_so(self.h, _ptr(d_cost), w, h, nb, row_elems, _ptr(d_ref), img_pitch,
                                       img_bands, smoothness, grad_thresh, grad_penalty, _ptr(d_disp),
                                       _ptr(d_best)))
+
+    def opt_dp(self, d_cost, w, h, nb, row_elems, d_ref, img_pitch, img_bands, smoothness, grad_thresh,
+               grad_penalty, occlusion_cost, d_disp, d_best):
+        self._chk(self.L.smhip_opt_dp(self.h, _ptr(d_cost), w, h, nb, row_elems, _ptr(d_ref), img_pitch,
+                                      img_bands, smoothness, grad_thresh, grad_penalty, int(occlusion_cost),
+                                      _ptr(d_disp), _ptr(d_best)))
 
     def keys_decode(self, d_keys, width, height, d_disp, d_best):
         """d_keys: width*height int64, column-major (pixel (x, y) at x*height + y)."""

@@ -399,9 +399,25 @@ void CStereoMatcher::OptSO()
                        opt_grad_thresh, opt_grad_penalty, (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
 }
 
+void CStereoMatcher::OptDP()
+{
+    if (m_disp_step != 1.0f)                                  // StcOptDP.cpp:112-114
+        fprintf(stderr, "WARNING: dynamic programming will not work properly for m_disp_step != 1\n");
+    Check(smhip_opt_dp(m_ctx, (const float *)m_dev[B_COST], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                       (const uint8_t *)m_dev[B_REF], m_reference.RowBytes(), m_mp.n_bands, opt_smoothness,
+                       opt_grad_thresh, opt_grad_penalty, opt_occlusion_cost, (int32_t *)m_dev[B_DISP],
+                       (float *)m_dev[B_BEST]));
+}
+
 void CStereoMatcher::Optimize()
 {
-    if (opt_fn == eScanlineOpt) {                             // StcOptimize.cpp:229-238, StcOptSO.cpp
+    if (opt_fn == eDynamicProg) {                             // StcOptimize.cpp:217-227, StcOptDP.cpp
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- computing smoothness costs (smoothness = %g, grad_thresh = %g, penalty=%g)\n"
+                            "- optimizing: Dynamic Programming (occlusion_cost = %d)\n",
+                    opt_smoothness, opt_grad_thresh, opt_grad_penalty, opt_occlusion_cost);
+        OptDP();
+    } else if (opt_fn == eScanlineOpt) {                             // StcOptimize.cpp:229-238, StcOptSO.cpp
         if (verbose >= eVerboseProgress)
             fprintf(stderr, "- computing smoothness costs (smoothness = %g, grad_thresh = %g, penalty=%g)\n"
                             "- optimizing: Scanline Optimization\n",
@@ -413,8 +429,8 @@ void CStereoMatcher::Optimize()
         if (!m_used_fused && !m_keys_done)
             OptWTA();
     } else {
-        throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) and 3 (scan-line optimisation) "
-                     "are on the device path");
+        throw CError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA), 2 (dynamic programming) and "
+                     "3 (scan-line optimisation) are on the device path");
     }
     // results to the host (disparity rows are 4*W bytes: already a multiple of 8 or padded here)
     size_t wbytes = (size_t)m_mp.width * 4;

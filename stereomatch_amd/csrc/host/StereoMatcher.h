@@ -36,6 +36,7 @@ protected:
     void PadCosts();
     void OptWTA();
     void OptSO();
+    void OptDP();
     void ComputeEnergy(float &denergy, float &nenergy);
     void ComputeOcclusions();
     void ComputeTextureless();

@@ -10,6 +10,7 @@
 #include "smhip_multi.h"
 #include "smhip_opt.h"
 #include "smhip_bayes.h"
+#include "smhip_dp.h"
 
 #include <math.h>
 #include <stdarg.h>
@@ -924,6 +925,45 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
     else if (nb <= 512) LAUNCH_SO(8);
     else                LAUNCH_SO(16);
 #undef LAUNCH_SO
+    if (d_best) {
+        long n_pix = (long)w * h;
+        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+            d_cost, w, h, nb, row_elems, d_disp, d_best);
+    }
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t row_elems,
+                 const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
+                 float opt_grad_thresh, float opt_grad_penalty, int opt_occlusion_cost, int32_t *d_disp,
+                 float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_ref || !d_disp || img_bands < 1 || img_pitch < (size_t)w * img_bands)
+        return fail(SMHIP_EINVAL, "OptDP: bad image / output arguments");
+    if (nb > 1024)
+        return fail(SMHIP_EINVAL, "OptDP: at most 1024 disparity levels (%d given)", nb);
+    void *smooth = nullptr, *trans = nullptr;
+    rc = ws_get(ctx, WS_BT, (size_t)w * h * sizeof(float), &smooth);
+    if (rc) return rc;
+    rc = ws_get(ctx, WS_TMP, (size_t)w * h * nb, &trans);
+    if (rc) return rc;
+    dim3 gs((w + 255) / 256, h);
+    smk::smooth_h_kernel<<<gs, 256, 0, ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
+                                                     opt_grad_thresh, opt_grad_penalty, (float *)smooth);
+    const float oc = (float)opt_occlusion_cost;      // ocL = ocR, StcOptDP.cpp:116-117
+#define LAUNCH_DP(NV) smk::opt_dp_kernel<NV><<<h, 64, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, \
+        (const float *)smooth, oc, (uint8_t *)trans, d_disp)
+    if (nb <= 64)       LAUNCH_DP(1);
+    else if (nb <= 128) LAUNCH_DP(2);
+    else if (nb <= 256) LAUNCH_DP(4);
+    else if (nb <= 512) LAUNCH_DP(8);
+    else                LAUNCH_DP(16);
+#undef LAUNCH_DP
     if (d_best) {
         long n_pix = (long)w * h;
         smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(

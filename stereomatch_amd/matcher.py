@@ -15,7 +15,7 @@ from . import capi
 eAD, eSD = 1, 2
 eLinear, eCubic = 1, 3
 eBox, eBinomial, eDiffusion, eMembrane, eBayesian = 1, 2, 3, 4, 5
-eNoOpt, eWTA, eScanlineOpt = 0, 1, 3
+eNoOpt, eWTA, eDynamicProg, eScanlineOpt = 0, 1, 2, 3
 
 
 def _round(x):  # ROUND, StereoMatcher.cpp:36
@@ -50,6 +50,7 @@ class StereoParameters:
         self.diff_sigmaP, self.diff_epsP = 0.4, 0.01
         self.opt_fn = eWTA
         self.opt_smoothness, self.opt_grad_thresh, self.opt_grad_penalty = 1.0, 5.0, 1.0
+        self.opt_occlusion_cost = 20
         self.refine_subpix = 0
         self.eval_match_quality = 0
         self.preproc_blur_iter = 0
@@ -251,16 +252,21 @@ class StereoMatcher(StereoParameters):
         self.d_cost, self.d_mind = cost2, mind2          # :227-229
         self.m_disp_n, self.m_row_elems, self.m_disp_step = n2, re2, np.float32(1.0)
 
-    def Optimize(self):  # StcOptimize.cpp:162-280: WTA and scan-line optimisation
+    def Optimize(self):  # StcOptimize.cpp:162-280: WTA and the two scan-line optimisers
         p = self.m_params
         if self.opt_fn == eScanlineOpt:                                  # OptSO, StcOptSO.cpp
             self.ctx.opt_so(self.d_cost, p.width, p.height, self.m_disp_n, self.m_row_elems, self.d_ref,
                             self.m_pitch, p.n_bands, self.opt_smoothness, self.opt_grad_thresh,
                             self.opt_grad_penalty, self.d_disp, self.d_best)
             return
+        if self.opt_fn == eDynamicProg:                                  # OptDP, StcOptDP.cpp
+            self.ctx.opt_dp(self.d_cost, p.width, p.height, self.m_disp_n, self.m_row_elems, self.d_ref,
+                            self.m_pitch, p.n_bands, self.opt_smoothness, self.opt_grad_thresh,
+                            self.opt_grad_penalty, self.opt_occlusion_cost, self.d_disp, self.d_best)
+            return
         if self.opt_fn != eWTA:
-            raise ValueError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA) and 3 (scan-line "
-                             "optimisation) are on the device path")
+            raise ValueError("CStereoMatcher::Optimize(): only opt_fn 1 (WTA), 2 (dynamic programming) "
+                             "and 3 (scan-line optimisation) are on the device path")
         if self.m_keys_done:
             return
         self.ctx.wta(self.d_cost, p.width, p.height, self.m_disp_n, self.m_row_elems, self.d_disp,

@@ -432,3 +432,28 @@ def test_bayesian_underflow_and_limits(gpu_ctx, oracle):
         gpu_ctx.bayesian_iter(big, es, e0, 2, 2, 129, 2 * 129, 1.0, 0.5, 0.4, 0.01, 0)
     with pytest.raises(capi.SmhipError, match="distinct"):
         gpu_ctx.bayesian_iter(es, es, e0, w, h, d, w * d, 1.0, 0.5, 0.4, 0.01, 0)
+
+
+@pytest.mark.parametrize("h,w,d,b", [(5, 40, 7, 1), (4, 33, 16, 4), (3, 50, 64, 1), (3, 50, 100, 1),
+                                     (3, 70, 65, 1), (3, 20, 200, 1), (2, 12, 300, 1), (2, 9, 2, 1),
+                                     (2, 1, 5, 1), (2, 30, 128, 1), (1, 150, 129, 4)])
+@pytest.mark.parametrize("par", [(20.0, 8.0, 2.0, 20), (5.0, 5.0, 1.0, 3), (0.0, 5.0, 1.0, 0),
+                                 (50.0, 8.0, 4.0, 80)])
+def test_opt_dp(gpu_ctx, oracle, h, w, d, b, par):
+    """smhip_opt_dp (wave per scan-line, systolic R chain) == the oracle's cell-by-cell restatement
+    of StcOptDP.cpp, bit for bit, with integer-valued costs (ties everywhere) and with fractional
+    ones (the additions of the occlusion cost do not commute) -- parity unpinned."""
+    rng = np.random.RandomState(300 + d)
+    c = rng.randint(0, 30, size=(h, w, d)).astype(np.float32)
+    c = np.where(rng.rand(h, w, d) < 0.4, (rng.rand(h, w, d) * 60).astype(np.float32), c)
+    img, _ = synth.noise_pair(w, h, b, seed=400 + d)
+    p = oracle.make_params(w, h, b, disp_max=max(d - 1, 1), opt_smoothness=par[0], opt_grad_thresh=par[1],
+                           opt_grad_penalty=par[2], opt_occlusion_cost=par[3])
+    want = oracle.opt_dp(c, img, p)
+    disp, best = gpu_ctx.alloc(h * w * 4), gpu_ctx.alloc(h * w * 4)
+    gpu_ctx.opt_dp(up(gpu_ctx, c), w, h, d, w * d, up(gpu_ctx, img), w * b, b, par[0], par[1], par[2], par[3],
+                   disp, best)
+    got = gpu_ctx.download(disp, (h, w), np.int32)
+    assert np.array_equal(got, want), "%d of %d pixels differ" % (np.sum(got != want), got.size)
+    gb = gpu_ctx.download(best, (h, w), np.float32)
+    util.assert_bit_equal(gb, np.take_along_axis(c, want[:, :, None], 2)[:, :, 0], "cost at the chosen level")

@@ -164,3 +164,26 @@ def test_bayesian_diffusion_vs_oracle(gpu_ctx, tsukuba, oracle):
     agree = np.mean(disp == odisp)
     assert agree >= 0.995, "winners agree on %.5f of the pixels" % agree
     assert np.mean(disp != oracle.wta(oracle.raw_costs(ref, mtc, p))[0]) > 0.05   # it did aggregate
+
+
+@pytest.mark.parametrize("kw", [
+    dict(opt_fn=2, match_fn=1, aggr_iter=0, opt_smoothness=20.0, opt_occlusion_cost=20),       # exp3 DPm1o20s0020
+    dict(opt_fn=2, match_fn=1, match_interval=1, match_max=10, aggr_iter=0, opt_smoothness=20.0,
+         opt_occlusion_cost=20),                                                               # ...bt10
+    dict(opt_fn=2, match_fn=1, aggr_iter=0, opt_smoothness=100.0, opt_occlusion_cost=80),      # exp5 DPm1o80s0100
+    dict(opt_fn=2, match_fn=2, aggr_window_size=5, opt_smoothness=50.0, opt_occlusion_cost=50),
+])
+def test_dynamic_programming_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
+    """opt_fn 2 (OptDP) end to end on tsukuba with settings of Scripts/exp3_costGlobal.txt:21-45 and
+    exp5_lambda.txt:17-50, plus one on box-filtered (fractional) costs; oracle only: the reference
+    holds no result image for these, parity unpinned."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+    odisp, obest, odepth, _ = oracle.compute_correspondence(ref, mtc, p)
+    m, disp, best, depth = run(gpu_ctx, tsukuba, kw)
+    assert not m.used_fused
+    util.assert_bit_equal(disp, odisp, "disparity")
+    util.assert_bit_equal(best, obest, "cost at the chosen level")
+    assert np.array_equal(depth, odepth)
+    assert np.mean(disp != oracle.wta(m.download_cost())[0]) > 0.01      # it is not just WTA
