@@ -62,6 +62,8 @@ def main():
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
     timed("opt_so (scan-line opt.)", 4.0 * N + 2.0 * N,
           lambda: ctx.opt_so(cost, W, H, D, re, d_ref, W, 1, 20.0, 8.0, 2.0, disp, best))
+    timed("opt_dp (dynamic programming)", 4.0 * N + 2.0 * N,
+          lambda: ctx.opt_dp(cost, W, H, D, re, d_ref, W, 1, 20.0, 8.0, 2.0, 20, disp, best))
     print(json.dumps({"shape": [W, H, D], "ops": out}))
 
 

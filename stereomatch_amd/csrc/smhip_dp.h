@@ -53,6 +53,7 @@ __global__ __launch_bounds__(64) void opt_dp_kernel(const float *__restrict__ co
     const float *sm = smooth + (size_t)y * W;
     int32_t *out = disp + (size_t)y * W;
     const float inf = __builtin_inff(), cmax = SMK_COST_MAX;
+    const float ocv = oc;                                     // in a VGPR for the DPP add
     auto load = [&](int x, float(&v)[NV]) {
 #pragma unroll
         for (int i = 0; i < NV; i++)
@@ -123,8 +124,25 @@ __global__ __launch_bounds__(64) void opt_dp_kernel(const float *__restrict__ co
             if (64 * i < D) {                                 // wave-uniform
                 float r = a[i];
                 const int steps = min(64, D - 64 * i);        // lanes past D-1 hold +inf already
-                for (int k = 0; k < steps; k++)
-                    r = fminf(a[i], lane_from_above(r, carry) + oc);
+                // r = min(a, r[lane+1] + oc) as two instructions: the DPP add leaves lane 63 of t
+                // alone (no source lane), where t keeps carry + oc; a VALU result needs two wait
+                // states before a DPP read
+                float t = carry + oc;
+                for (int k = 0; k < steps; k += 4)            // extra steps past the fixed point change nothing
+                    asm volatile("s_nop 1\n\t"
+                                 "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_min_f32 %1, %3, %0\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_min_f32 %1, %3, %0\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_min_f32 %1, %3, %0\n\t"
+                                 "s_nop 1\n\t"
+                                 "v_add_f32_dpp %0, %1, %2 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+                                 "v_min_f32 %1, %3, %0"
+                                 : "+v"(t), "+v"(r)
+                                 : "v"(ocv), "v"(a[i]));
                 Rn[i] = r;
                 carry = lane_value(r, 0);
             } else {
