@@ -818,6 +818,19 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
             else if (nv == 2) smk::wta_vec_kernel<2><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
             else if (nv == 3) smk::wta_vec_kernel<3><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
             else              smk::wta_vec_kernel<4><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+        } else if (nb >= 8 && h <= 65535) {
+            int seg = 2;                               // lanes per pixel: the power of two >= nb / 4
+            while (4 * seg < nb) seg *= 2;
+            dim3 grid((unsigned)(((size_t)w * seg + 255) / 256), h);
+#define LAUNCH_WS(S) smk::wta_seg_kernel<S><<<grid, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best)
+            switch (seg) {
+            case 2: LAUNCH_WS(2); break;
+            case 4: LAUNCH_WS(4); break;
+            case 8: LAUNCH_WS(8); break;
+            case 16: LAUNCH_WS(16); break;
+            default: LAUNCH_WS(32); break;
+            }
+#undef LAUNCH_WS
         } else {
             smk::wta_thread_vec_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
                 d_cost, w, h, nb, row_elems, d_disp, d_best);

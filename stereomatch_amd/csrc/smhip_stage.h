@@ -230,4 +230,58 @@ __global__ __launch_bounds__(256) void wta_thread_vec_kernel(const float *__rest
     if (best) best[p] = bc;
 }
 
+// D <= 128 (D % 4 == 0): SEG = 2..32 lanes per pixel, four levels per lane, so a wave reads its
+// piece of the DSI row in one coalesced sweep; the first minimum of the segment by three integer
+// DPP butterflies (ordered value, then lowest level holding it, then that lane's float).
+template <int CTRL>
+__device__ __forceinline__ int dpp_xmin(int v)
+{
+    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false));
+}
+template <int SEG>
+__device__ __forceinline__ int seg_min_all(int v)
+{
+    if (SEG >= 2)  v = dpp_xmin<0xB1>(v);                 // quad_perm [1,0,3,2]
+    if (SEG >= 4)  v = dpp_xmin<0x4E>(v);                 // quad_perm [2,3,0,1]
+    if (SEG >= 8)  v = dpp_xmin<0x141>(v);                // row_half_mirror
+    if (SEG >= 16) v = dpp_xmin<0x140>(v);                // row_mirror
+    if (SEG >= 32) v = min(v, __shfl_xor(v, 16, 64));
+    return v;
+}
+
+template <int SEG>
+__global__ __launch_bounds__(256) void wta_seg_kernel(const float *__restrict__ cost, int W, int H, int D,
+                                                      size_t row_elems, int32_t *__restrict__ disp,
+                                                      float *__restrict__ best)
+{
+    typedef typename fvec<4>::type vec;
+    const int y = blockIdx.y;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int x = t / SEG, sub = t % SEG;
+    const bool live = x < W && 4 * sub < D;
+    vec v = {0, 0, 0, 0};
+    if (live)
+        v = __builtin_nontemporal_load((const vec *)(cost + (size_t)y * row_elems + (size_t)x * D + 4 * sub));
+    int s = 0x7FFFFFFF, d = 0x7FFFFFFF;
+    float bv = 0;
+    if (live) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int o = ordered_bits(v[e]);
+            if (o < s) {
+                s = o;
+                d = 4 * sub + e;
+                bv = v[e];
+            }
+        }
+    }
+    const int smin = seg_min_all<SEG>(s);
+    const int dmin = seg_min_all<SEG>(s == smin ? d : 0x7FFFFFFF);
+    const int bits = seg_min_all<SEG>(d == dmin ? __float_as_int(bv) : 0x7FFFFFFF);
+    if (sub == 0 && x < W) {
+        if (disp) disp[(size_t)y * W + x] = dmin;
+        if (best) best[(size_t)y * W + x] = __int_as_float(bits);
+    }
+}
+
 }  // namespace smk

@@ -189,7 +189,8 @@ def test_diffusion(gpu_ctx, oracle, h, w, d, pad, beta):
 
 @pytest.mark.parametrize("h,w,d", [(6, 20, 7), (5, 9, 64), (4, 11, 100), (3, 7, 256), (3, 5, 300),
                                    (3, 37, 128), (5, 19, 512), (3, 9, 1024), (3, 9, 640), (3, 5, 1100),
-                                   (4, 7, 132)])
+                                   (4, 7, 132), (4, 70, 8), (5, 130, 16), (4, 33, 20), (4, 41, 32),
+                                   (4, 29, 40), (4, 70, 60), (4, 23, 96), (4, 19, 124), (4, 50, 4)])
 def test_wta(gpu_ctx, oracle, h, w, d):
     c = util.rand_dsi(h, w, d, 50)
     c[0, 0, :] = 5.0
