@@ -99,3 +99,39 @@ void WriteImage(const CByteImage &img, const char *filename)
         }
     }
 }
+
+void ReadImage(CFloatImage &img, const char *filename)
+{
+    if (!ends_with(filename, ".pmf"))
+        throw CError("ReadImage(%s): a float image is read from a .pmf file", filename);
+    File in(filename, "rb");
+    if (!in.f)
+        throw CError("ReadImage: could not open %s", filename);
+    if (getc(in.f) != 'P' || getc(in.f) != '9')
+        throw CError("ReadImage(%s): wrong magic code for PMF file", filename);
+    int w = next_int(in.f, filename), h = next_int(in.f, filename), b = next_int(in.f, filename);
+    int c = getc(in.f);
+    if (c == '\r') c = getc(in.f);
+    if (c != '\n')
+        throw CError("ReadImage(%s): newline expected after the header", filename);
+    img.ReAllocate(CShape(w, h, b));
+    size_t n = (size_t)w * b * sizeof(float);
+    for (int y = 0; y < h; y++)
+        if (fread(img.Row(y), 1, n, in.f) != n)
+            throw CError("ReadImage(%s): file is too short", filename);
+}
+
+void WriteImage(const CFloatImage &img, const char *filename)
+{
+    if (!ends_with(filename, ".pmf"))
+        throw CError("WriteImage(%s): can only write floating point image as pmf", filename);
+    CShape sh = img.Shape();
+    File out(filename, "wb");
+    if (!out.f)
+        throw CError("WriteImage: could not open %s", filename);
+    fprintf(out.f, "P9\n%d %d\n%d\n", sh.width, sh.height, sh.nBands);
+    size_t n = (size_t)sh.width * sh.nBands * sizeof(float);
+    for (int y = 0; y < sh.height; y++)
+        if (fwrite(img.Row(y), 1, n, out.f) != n)
+            throw CError("WriteImage(%s): write failed", filename);
+}

@@ -114,8 +114,18 @@ int CStereoIO::InterpretCommandLine(int argc, const char *argv[])
 
 void CStereoIO::RunMatcher()
 {
-    if (depth_map[0])
+    if (depth_map[0]) {
+        // cost_map ("cost map (DSI), for debugging", StereoIO.h:85 -- declared but unused in the
+        // reference): here it names the file the aggregated DSI is written to, one PGM per level
+        // ("..._%03d.pgm") or the whole volume as one .pmf; the DSI has to exist for that
+        bool fused = allow_fused;
+        if (cost_map[0])
+            allow_fused = false;
         ComputeCorrespondence();
+        allow_fused = fused;
+        if (cost_map[0])
+            WriteCosts(cost_map);
+    }
     if (output_params[0])
         Evaluate();
 }

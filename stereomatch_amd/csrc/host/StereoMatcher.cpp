@@ -2,7 +2,9 @@
 // StcAggregate.cpp:66-230, 255-400, StcOptimize.cpp:162-280, StcRefine.cpp:28-100) over the C-ABI.
 #include "StereoMatcher.h"
 #include "Error.h"
+#include "ImageIO.h"
 #include <cmath>
+#include <cstring>
 #include <ctime>
 
 #define ROUND(x) ((int)((x) >= 0 ? (x) + .5 : (x) - .5))
@@ -208,6 +210,42 @@ void CStereoMatcher::RawCosts()
         return;                                               // made inside AggrBox
     Check(smhip_raw_costs(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
                           m_reference.RowBytes(), &m_mp, (float *)m_dev[B_COST], m_row_elems));
+    if (verbose >= eVerboseDumpFiles)                         // StcRawCosts.cpp:421-422
+        WriteCosts("reprojected/RAW_DSI_%03d.pgm");
+}
+
+// WriteCosts (StcAggregate.cpp:27-52): the resident DSI comes back to the host and goes out as
+// one PGM per level, scaled by 2 and clipped (ScaleAndOffset float -> uchar, Convert.cpp:33-40);
+// a name ending in .pmf writes the whole DSI losslessly instead (the CAN_VIEW_PMFS branch, :29-35).
+void CStereoMatcher::WriteCosts(const char *filename)
+{
+    int w = m_mp.width, h = m_mp.height, nd = m_disp_n;
+    CFloatImage cost(w, h, nd);
+    size_t wbytes = (size_t)w * nd * sizeof(float);
+    Check(smhip_memcpy2d_d2h(m_ctx, cost.Data(), cost.RowBytes(), m_dev[B_COST], m_row_elems * sizeof(float),
+                             wbytes, h));
+    size_t len = strlen(filename);
+    if (len >= 4 && strcmp(filename + len - 4, ".pmf") == 0) {
+        WriteImage(cost, filename);
+        return;
+    }
+    const float scaleUp = 2;
+    CByteImage plane(w, h, 1);
+    for (int d = 0; d < nd; d++) {
+        char name[1024];
+        snprintf(name, sizeof(name), filename, d);
+        for (int y = 0; y < h; y++) {
+            const float *src = cost.Row(y);
+            uchar *dst = plane.Row(y);
+            for (int x = 0; x < w; x++) {
+                float v = src[(size_t)x * nd + d] * scaleUp + 0.0f;
+                v = v < 0.0f ? 0.0f : v;
+                v = v > 255.0f ? 255.0f : v;
+                dst[x] = (uchar)v;
+            }
+        }
+        WriteImage(plane, name);
+    }
 }
 
 void CStereoMatcher::AggrBox()
@@ -345,6 +383,8 @@ void CStereoMatcher::Aggregate()
             fprintf(stderr, "- collapse to integral DSI\n");
         AggrCollapse();
     }
+    if (verbose >= eVerboseDumpFiles)                         // :403-404
+        WriteCosts("reprojected/DSIa_%03d.pgm");
 }
 
 void CStereoMatcher::AggrSubPixelFit()

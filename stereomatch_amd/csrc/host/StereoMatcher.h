@@ -47,6 +47,7 @@ protected:
     void Check(int rc);                 // smhip status -> CError
     void *DeviceBuffer(int slot, size_t bytes);
     void SwapCost();
+    void WriteCosts(const char *filename);
     bool Fusable() const;
 
     smhip_ctx *m_ctx = nullptr;

@@ -1,4 +1,4 @@
-"""PGM / PPM reader and writer with the reference's in-memory conventions.
+"""PGM / PPM / PMF reader and writer with the reference's in-memory conventions.
 
 ReadFilePGM (ImageIO.cpp:333-402): P5 -> 1 band; P6 -> 4 bands stored B,G,R,A with
 A = 255 (:390-396).  WriteFilePGM (ImageIO.cpp:406-486): header "P5\\n%d %d\\n255\\n"
@@ -33,7 +33,8 @@ def _read_header(f, magic):
 
 
 def read_image(path):
-    """Returns uint8 [H, W, nBands] with nBands = 1 (.pgm) or 4 (.ppm, BGRA)."""
+    """Returns uint8 [H, W, nBands] with nBands = 1 (.pgm) or 4 (.ppm, BGRA), or float32
+    [H, W, nBands] for a .pmf (the reference's multi-band float container, e.g. a DSI)."""
     with open(path, "rb") as f:
         if path.endswith(".pgm"):
             w, h, _ = _read_header(f, b"P5")
@@ -53,6 +54,13 @@ def read_image(path):
             out[..., 2] = rgb[..., 0]
             out[..., 3] = 255
             return out
+        if path.endswith(".pmf"):
+            # P9: width, height, bands, then rows of native floats (ImageIO.cpp:352-376)
+            w, h, b = _read_header(f, b"P9")
+            data = np.frombuffer(f.read(w * h * b * 4), np.float32)
+            if data.size != w * h * b:
+                raise ValueError("%s: file is too short" % path)
+            return data.reshape(h, w, b).copy()
     raise ValueError("%s: unsupported extension" % path)
 
 
@@ -68,3 +76,17 @@ def pgm_bytes(img):
 def write_pgm(path, img):
     with open(path, "wb") as f:
         f.write(pgm_bytes(img))
+
+
+def pmf_bytes(img):
+    """Bytes of the file WriteFilePGM writes for a float image (ImageIO.cpp:428-441)."""
+    img = np.ascontiguousarray(img, np.float32)
+    if img.ndim == 2:
+        img = img[..., None]
+    h, w, b = img.shape
+    return b"P9\n%d %d\n%d\n" % (w, h, b) + img.tobytes()
+
+
+def write_pmf(path, img):
+    with open(path, "wb") as f:
+        f.write(pmf_bytes(img))

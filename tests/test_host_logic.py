@@ -48,3 +48,17 @@ def test_parameter_defaults():
     assert (p.match_fn, p.match_interp, p.match_max, p.match_interval) == (1, 3, 1000, 0)
     assert (p.aggr_fn, p.aggr_window_size, p.aggr_iter, p.aggr_minfilter) == (1, 7, 1, 0)
     assert abs(p.diff_lambda - 0.15) < 1e-9 and p.diff_beta == 0.5 and p.opt_fn == 1
+
+
+def test_pmf_roundtrip(tmp_path):
+    """PMF (P9): width, height, bands, native float rows (ImageIO.cpp:352-376, :428-441)."""
+    rng = np.random.RandomState(5)
+    a = rng.randn(7, 5, 3).astype(np.float32)
+    a[0, 0, 0] = -0.0
+    path = str(tmp_path / "x.pmf")
+    pnm.write_pmf(path, a)
+    raw = open(path, "rb").read()
+    assert raw.startswith(b"P9\n5 7\n3\n") and len(raw) == 9 + a.nbytes
+    b = pnm.read_image(path)
+    assert b.dtype == np.float32 and b.shape == a.shape
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
