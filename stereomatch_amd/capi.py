@@ -60,11 +60,35 @@ def match_params(width, height, n_bands, disp_n, disp_min=0, disp_num=1, disp_de
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  Two HIP runtimes in one process do
+    not share the GPU: whichever loads second finds no device (measured: `import torch` after
+    libsmhip.so had pulled in /opt/rocm's runtime gives torch.cuda.is_available() == False).
+    So when a torch with a bundled runtime is installed, that copy is loaded first and
+    libsmhip.so binds to it (same soname) -- the import order of torch and this module then does
+    not matter.  Nothing of torch itself is imported here."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        return None
+
+
 def load():
     """Loads libsmhip.so and declares prototypes.  Raises if the library is absent."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -63,16 +63,17 @@ class KeyReducePipeline:
     rewritten before its consumer ran.  Call flush() after the last frame.
     """
 
-    def __init__(self, key_buffers, produce, consume, group=None):
+    def __init__(self, key_buffers, produce, consume, group=None, force_collective=False):
         if len(key_buffers) != 2:
             raise ValueError("KeyReducePipeline needs exactly two key buffers")
         self.bufs, self.produce, self.consume, self.group = key_buffers, produce, consume, group
+        self.force_collective = force_collective    # issue the all-reduce even in a group of one (tests)
         self.n = 0
         self.pending = None
 
     def _reduce_async(self, buf):
         import torch.distributed as dist
-        if dist.is_initialized() and dist.get_world_size(self.group) > 1:
+        if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force_collective):
             return dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
         return None
 
