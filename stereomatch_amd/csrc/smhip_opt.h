@@ -50,6 +50,16 @@ __device__ __forceinline__ void wave_first_min(int bo, int bi, int &mo, int &mi)
     mi = wave_min_i32(bo == mo ? bi : 0x7FFFFFFF);
 }
 
+// the same when lane order is level order (a lower lane holds lower levels, bi = the lane's own
+// first minimum): the owner is the first lane holding the minimum -- a ballot instead of a second
+// DPP reduction
+__device__ __forceinline__ void wave_first_min_ordered(int bo, int bi, int &mo, int &mi)
+{
+    mo = wave_min_i32(bo);
+    const unsigned long long owners = __ballot(bo == mo);
+    mi = __builtin_amdgcn_readlane(bi, __ffsll((long long)owners) - 1);
+}
+
 // m_cost at the chosen level (the data term of final_energy reads it): one thread per pixel
 __global__ void gather_best_kernel(const float *__restrict__ cost, int W, int H, int D, size_t row_elems,
                                    const int32_t *__restrict__ disp, float *__restrict__ best)
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
         }
         int m1, i1, m2, i2;
         short tv[NV];
-        wave_first_min(bo, bi, m1, i1);
+        wave_first_min_ordered(bo, bi, m1, i1);
         bo = 0x7FFFFFFF;
         bi = 0x7FFFFFFF;
 #pragma unroll
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
                 bo = to[i];
                 bi = d0 + i;
             }
-        wave_first_min(bo, bi, m2, i2);
+        wave_first_min_ordered(bo, bi, m2, i2);
 #pragma unroll
         for (int i = 0; i < NV; i++) {
             const int d = d0 + i;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(64) void opt_so_kernel(const float *__restrict__ co
         }
     }
     int mo, mi;
-    wave_first_min(bo, bi, mo, mi);
+    wave_first_min_ordered(bo, bi, mo, mi);
     if (!(unordered_bits(mo) < SMK_COST_MAX))
         mi = 0;
     // backtrack (:144-151): the transitions of this row were written by this wave
