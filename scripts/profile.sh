@@ -7,7 +7,7 @@ tag=${1:-run}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra"
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -- $BENCH > $out/kt.log 2>&1 || { echo "kernel-trace failed"; tail -5 $out/kt.log; exit 1; }
 timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $out/pmc1 -- $BENCH > $out/pmc1.log 2>&1 || { echo "pmc1 failed"; tail -5 $out/pmc1.log; exit 1; }
 timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $out/pmc2 -- $BENCH > $out/pmc2.log 2>&1 || { echo "pmc2 failed"; tail -5 $out/pmc2.log; exit 1; }
