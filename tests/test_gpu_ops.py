@@ -364,7 +364,8 @@ def test_preprocess_blur(gpu_ctx, oracle, w, h, b, iters):
 
 
 @pytest.mark.parametrize("h,w,d,b", [(5, 40, 7, 1), (4, 33, 16, 4), (3, 50, 100, 1), (3, 20, 200, 1),
-                                     (2, 12, 300, 1), (2, 9, 1, 1), (2, 1, 5, 1)])
+                                     (2, 12, 300, 1), (2, 9, 1, 1), (2, 1, 5, 1), (2, 10, 520, 1),
+                                     (1, 6, 1024, 1)])
 @pytest.mark.parametrize("smooth", [(1.0, 5.0, 1.0), (20.0, 8.0, 2.0), (0.0, 5.0, 1.0)])
 def test_opt_so(gpu_ctx, oracle, h, w, d, b, smooth):
     """smhip_opt_so (O(D) per pixel, wave minima) == the reference's O(D^2) scan restated in the
@@ -437,7 +438,8 @@ def test_bayesian_underflow_and_limits(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("h,w,d,b", [(5, 40, 7, 1), (4, 33, 16, 4), (3, 50, 64, 1), (3, 50, 100, 1),
                                      (3, 70, 65, 1), (3, 20, 200, 1), (2, 12, 300, 1), (2, 9, 2, 1),
-                                     (2, 1, 5, 1), (2, 30, 128, 1), (1, 150, 129, 4)])
+                                     (2, 1, 5, 1), (2, 30, 128, 1), (1, 150, 129, 4), (2, 10, 520, 1),
+                                     (1, 6, 1024, 1)])
 @pytest.mark.parametrize("par", [(20.0, 8.0, 2.0, 20), (5.0, 5.0, 1.0, 3), (0.0, 5.0, 1.0, 0),
                                  (50.0, 8.0, 4.0, 80)])
 def test_opt_dp(gpu_ctx, oracle, h, w, d, b, par):
