@@ -1048,14 +1048,12 @@ int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_
     long n_pix = (long)w * h;
     unsigned blocks = (unsigned)((n_pix + 3) / 4 < 4096 ? (n_pix + 3) / 4 : 4096);
     float *e0 = iter == 0 ? d_cost0 : nullptr;
-    if (DP == 64)
-        smk::bayes_smooth_kernel<1><<<blocks, 256, 0, ctx->stream>>>(d_cost, d_cost2, e0, scale_cost, ctx->bayes_w,
-                                                                    ctx->bayes_w + band_cap, ctx->bayes_band, w, h,
-                                                                    nb, row_elems);
-    else
-        smk::bayes_smooth_kernel<2><<<blocks, 256, 0, ctx->stream>>>(d_cost, d_cost2, e0, scale_cost, ctx->bayes_w,
-                                                                    ctx->bayes_w + band_cap, ctx->bayes_band, w, h,
-                                                                    nb, row_elems);
+#define LAUNCH_BS(S, HB) smk::bayes_smooth_kernel<S, HB><<<blocks, 256, 0, ctx->stream>>>( \
+        d_cost, d_cost2, e0, scale_cost, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h, nb, row_elems)
+    const bool narrow = ctx->bayes_band <= 6;        // sigmaP up to about 0.5: the band lives in registers
+    if (DP == 64) { if (narrow) LAUNCH_BS(1, 6); else LAUNCH_BS(1, 0); }
+    else          { if (narrow) LAUNCH_BS(2, 6); else LAUNCH_BS(2, 0); }
+#undef LAUNCH_BS
     dim3 ge((w * nb + 255) / 256, h);
     smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(d_cost, d_cost2, d_cost0, w, nb, h, row_elems, mu);
     HIP_TRY(hipGetLastError());

@@ -5,8 +5,8 @@
 //   3. Es(d) = -log(max(1e-16, Ps(d)))                          (double log, stored as float)
 //   4. E     = E0 + mu * (Es + left + right + up + down)        (float, 5-point, replicate border)
 //
-// TOLERANCE MODE: steps 1 and 3 call the device's expf / log, which differ from the host libm
-// the reference uses in the last place (and the host's own result depends on which libm variant
+// TOLERANCE MODE: steps 1 and 3 use the device's expf and a short series for log, which differ
+// from the host libm the reference uses in the last place (and the host's own result depends on which libm variant
 // the CPU selects), so this operator is not bit-exact -- every other operator of the library is.
 //
 // Step 2 is a D x D product per pixel, but the matrix is a band plus a constant: beyond
@@ -31,12 +31,48 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// 1 / d to about an ulp: hardware seed + two Newton steps (tolerance mode: the reference divides)
+__device__ __forceinline__ double fast_rcp_f64(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+// -log(x) for a normal positive double: x = m * 2^e with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(z), z = (m - 1) / (m + 1), |z| <= 0.172, odd series up to z^15 (next term
+// 3e-14 relative) -- a quarter of the library routine's instructions, far inside the float
+// rounding of the stored energy.
+__device__ __forceinline__ double neg_log_f64(double x)
+{
+    const long long b = __double_as_longlong(x);
+    int e = (int)((b >> 52) & 0x7FF) - 1023;
+    double m = __longlong_as_double((b & 0x000FFFFFFFFFFFFFll) | 0x3FF0000000000000ll);
+    if (m > 1.4142135623730951) {
+        m *= 0.5;
+        e += 1;
+    }
+    const double z = (m - 1.0) * fast_rcp_f64(m + 1.0);
+    const double z2 = z * z;
+    double p = 1.0 / 15.0;
+    p = fma(p, z2, 1.0 / 13.0);
+    p = fma(p, z2, 1.0 / 11.0);
+    p = fma(p, z2, 1.0 / 9.0);
+    p = fma(p, z2, 1.0 / 7.0);
+    p = fma(p, z2, 1.0 / 5.0);
+    p = fma(p, z2, 1.0 / 3.0);
+    p = fma(p, z2, 1.0);
+    return -fma((double)e, 0.6931471805599453, 2.0 * z * p);
+}
+
 constexpr int BAYES_MAXD = 128;          // == SMHIP_BAYES_MAX_LEVELS
 constexpr int BAYES_LINE = 3 * BAYES_MAXD;
 
 // steps 1-3: E -> Es.  wb = band [(2B+1)][64*SLOTS] of (w - e_d), zero outside the matrix;
 // ed = e_d per level.  E0 != nullptr (first iteration): E *= scale first, and E0 = E (:182-191).
-template <int SLOTS>
+// HB > 0: bands up to half-width HB are held in registers for the whole kernel (the weights
+// depend on the level only); HB = 0: any band, weights read in the loop.
+template <int SLOTS, int HB>
 __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E, float *__restrict__ Es,
                                                            float *__restrict__ E0, float scale,
                                                            const double *__restrict__ wb,
@@ -52,9 +88,25 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
     const int dA = lane, dB = lane + 64;
     const bool inA = dA < D, inB = SLOTS > 1 && dB < D;
     const double edA = inA ? ed[dA] : 0.0, edB = inB ? ed[dB] : 0.0;
-    const long n_pix = (long)W * H, n_waves = (long)gridDim.x * 4;
-    for (long pix = (long)blockIdx.x * 4 + wave; pix < n_pix; pix += n_waves) {   // wave-uniform
-        const int y = (int)(pix / W), x = (int)(pix - (long)y * W);
+    double wA[2 * HB + 1], wB[2 * HB + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * HB + 1; j++) {
+        const int k = j - HB;
+        const bool in = HB > 0 && k >= -B && k <= B;
+        wA[j] = in ? wb[(size_t)(k + B) * DP + dA] : 0.0;
+        wB[j] = in && SLOTS > 1 ? wb[(size_t)(k + B) * DP + dB] : 0.0;
+    }
+    // wave-uniform walk over the pixels, (x, y) stepped without a division per pixel
+    const int n_waves = (int)gridDim.x * 4, first = (int)blockIdx.x * 4 + wave;
+    const int step_y = n_waves / W, step_x = n_waves - step_y * W;
+    int y = first / W, x = first - y * W;
+    for (; y < H; x += step_x, y += step_y) {
+        if (x >= W) {
+            x -= W;
+            y++;
+            if (y >= H)
+                break;
+        }
         const size_t o = (size_t)y * row_elems + (size_t)x * D;
         float eA = inA ? E[o + dA] : 0.0f, eB = inB ? E[o + dB] : 0.0f;
         if (E0) {
@@ -70,8 +122,9 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
             pA = inA ? 1.0 / D : 0.0;
             pB = inB ? 1.0 / D : 0.0;
         } else {
-            pA /= s;
-            pB /= s;
+            const double rs = fast_rcp_f64(s);
+            pA *= rs;
+            pB *= rs;
         }
         __builtin_amdgcn_wave_barrier();                    // the previous pixel's reads are done
         if (inA) pl[BAYES_MAXD + dA] = pA;
@@ -79,16 +132,25 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         double psA = edA, psB = edB;                        // :247-250, band + constant
-        const double *wk = wb;
-        for (int k = -B; k <= B; k++, wk += DP) {
-            psA = fma(wk[dA], pl[BAYES_MAXD + dA + k], psA);
-            if (SLOTS > 1)
-                psB = fma(wk[dB], pl[BAYES_MAXD + dB + k], psB);
+        if (HB > 0) {
+#pragma unroll
+            for (int j = 0; j < 2 * HB + 1; j++) {
+                psA = fma(wA[j], pl[BAYES_MAXD + dA + j - HB], psA);
+                if (SLOTS > 1)
+                    psB = fma(wB[j], pl[BAYES_MAXD + dB + j - HB], psB);
+            }
+        } else {
+            const double *wk = wb;
+            for (int k = -B; k <= B; k++, wk += DP) {
+                psA = fma(wk[dA], pl[BAYES_MAXD + dA + k], psA);
+                if (SLOTS > 1)
+                    psB = fma(wk[dB], pl[BAYES_MAXD + dB + k], psB);
+            }
         }
         if (inA)
-            Es[o + dA] = (float)(-log(1e-16 > psA ? 1e-16 : psA));   // :253
+            Es[o + dA] = (float)neg_log_f64(1e-16 > psA ? 1e-16 : psA);   // :253
         if (inB)
-            Es[o + dB] = (float)(-log(1e-16 > psB ? 1e-16 : psB));
+            Es[o + dB] = (float)neg_log_f64(1e-16 > psB ? 1e-16 : psB);
     }
 }
 
