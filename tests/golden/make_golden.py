@@ -2,7 +2,8 @@
 
 `reference`: values recorded from the reference's own CPU path (they are
 copied here verbatim, this script does not run the reference).  `oracle`: md5 of the disparity
-PGM that oracle/sm_oracle.c produces for every exp1 / exp2 / exp4-style configuration.
+PGM that oracle/sm_oracle.c produces for every exp1 / exp2 / exp4-style configuration, and CRC-32
+of the aggregated DSI (raw float bytes) per stage operator.
 Run from the repository root:  python tests/golden/make_golden.py
 """
 import json
@@ -47,6 +48,10 @@ def main():
         out["oracle"]["final_energy"][name] = e
         ev = O.evaluate(fd, truth, ref, p, **util.TSUKUBA_EVAL)
         out["oracle"]["evaluator"][name] = {k: "%f" % v for k, v in ev.items()}   # as results/*.txt prints
+    out["oracle"]["dsi_crc32"] = {}
+    for name, kw in util.stage_cases():
+        p = O.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+        out["oracle"]["dsi_crc32"][name] = util.crc32(O.aggregate(O.raw_costs(ref, mtc, p), p))
     with open(os.path.join(ROOT, "tests", "golden", "tsukuba_anchors.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote %d oracle vectors" % len(out["oracle"]["md5"]))

@@ -187,3 +187,11 @@ def test_dynamic_programming_vs_oracle(gpu_ctx, tsukuba, oracle, kw):
     util.assert_bit_equal(best, obest, "cost at the chosen level")
     assert np.array_equal(depth, odepth)
     assert np.mean(disp != oracle.wta(m.download_cost())[0]) > 0.01      # it is not just WTA
+
+
+def test_stage_dsi_checksums(gpu_ctx, tsukuba):
+    """The device's aggregated DSI against the committed per-stage checksums (no oracle in the loop)."""
+    want = util.anchors()["oracle"]["dsi_crc32"]
+    for name, kw in util.stage_cases():
+        m, _, _, _ = run(gpu_ctx, tsukuba, kw, fused=False)
+        assert util.crc32(m.download_cost()) == want[name], name

@@ -201,3 +201,15 @@ def test_evaluator_reproduces_recorded_statistics(oracle, tsukuba):
     ev = oracle.evaluate(fd, truth, ref, p, **util.TSUKUBA_EVAL)
     for k, v in util.anchors()["reference"]["evaluator"]["SSD09"].items():
         assert "%f" % ev[k] == v, k
+
+
+def test_stage_dsi_checksums(oracle, tsukuba):
+    """Per-stage DSI checksums (CRC-32 of the float bytes after Aggregate) committed with the golden
+    vectors: the oracle keeps producing the same volumes, bit for bit."""
+    ref, mtc = tsukuba
+    h, w, b = ref.shape
+    want = util.anchors()["oracle"]["dsi_crc32"]
+    assert set(want) == {n for n, _ in util.stage_cases()}
+    for name, kw in util.stage_cases():
+        p = oracle.make_params(w, h, b, **util.TSUKUBA_SEQ, **kw)
+        assert util.crc32(oracle.aggregate(oracle.raw_costs(ref, mtc, p), p)) == want[name], name

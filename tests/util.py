@@ -63,3 +63,25 @@ def exp4_grid():
     out += [("SADdiff%02d" % it, dict(match_fn=1, aggr_fn=3, aggr_iter=it)) for it in (1, 10)]
     out += [("SADmem10b05", dict(match_fn=1, aggr_fn=4, aggr_iter=10, diff_beta=0.5))]
     return out
+
+
+def stage_cases():
+    """Configurations whose aggregated DSI (after PadCosts) is pinned by a CRC-32 of its float bytes
+    in tests/golden/tsukuba_anchors.json ("dsi_crc32"): one per stage operator of the path."""
+    return [
+        ("raw_SSD", dict(match_fn=2, aggr_iter=0)),
+        ("raw_SADb_t20", dict(match_fn=1, match_interval=1, match_max=20, aggr_iter=0)),
+        ("raw_SAD_interp_half", dict(match_fn=1, match_interpolated=1, match_interval=1, disp_step=0.5, aggr_iter=0)),
+        ("box9_SSD", dict(match_fn=2, aggr_window_size=9)),
+        ("box5x2_SAD", dict(match_fn=1, aggr_window_size=5, aggr_iter=2)),
+        ("box9_min9_SSD_t20", dict(match_fn=2, match_max=20, aggr_window_size=9, aggr_minfilter=9)),
+        ("binomial4_SAD", dict(match_fn=1, aggr_fn=2, aggr_iter=4)),
+        ("diffusion10_SAD", dict(match_fn=1, aggr_fn=3, aggr_iter=10, diff_lambda=0.15)),
+        ("membrane3_SADb", dict(match_fn=1, match_interval=1, aggr_fn=4, aggr_iter=3, diff_lambda=0.15, diff_beta=0.5)),
+    ]
+
+
+def crc32(a):
+    import zlib
+    import numpy as np
+    return "%08x" % (zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
