@@ -100,7 +100,9 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
 
 /* Replaces CudaBoxFilterXY (CudaBoxFilter.h:31-32, called from BoxFilter.cpp:197) with the
  * semantics of the CPU BoxFilter<float> (BoxFilter.cpp:173-239): any window, running sum,
- * replicate border, in place.  x_width != y_width is rejected like BoxFilter.cpp:179-180. */
+ * replicate border, in place.  x_width != y_width is rejected like BoxFilter.cpp:179-180.
+ * Windows larger than the image width or height are refused (SMHIP_EINVAL): there the reference's
+ * running sum reads beyond the line (BoxFilter.cpp:114-124) or trips its double-wrapping asserts. */
 int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
                      size_t row_elems, int x_width, int y_width, int average);
 

@@ -439,7 +439,10 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     int win = x_width;
     if (win < 1)
         return fail(SMHIP_EINVAL, "BoxFilter: bad window %d", win);
-    if (win - win / 2 >= w || win - win / 2 >= h)   // borderIndex asserts, BoxFilter.cpp:37,51
+    // the reference's running sum reads src[x + pr] unchecked for x < -pl (BoxFilter.cpp:114-124),
+    // i.e. up to index w - 1, and asserts against double wrapping (:37, :51): lines shorter than
+    // the window are outside its domain
+    if (win > w || win > h)
         return fail(SMHIP_EINVAL, "BoxFilter: window %d too large for %dx%d (double wrapping)", win, w, h);
     void *tmp = nullptr;
     rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
@@ -1094,7 +1097,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count,
                     p->disp_n);
     int W = p->width, H = p->height;
-    if (window < 1 || window - window / 2 >= W || window - window / 2 >= H)
+    if (window < 1 || window > W || window > H)           // as smhip_box_filter
         return fail(SMHIP_EINVAL, "BoxFilter: window %d unusable for %dx%d", window, W, H);
 
     // padded slab width Dp: a power of two below 64 (narrow kernels), else 64 / 128 / 256 with

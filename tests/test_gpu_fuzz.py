@@ -1,0 +1,80 @@
+"""Seeded differential test of the whole device pipeline against the oracle: random image shapes,
+band counts, disparity ranges / steps / directions, matching costs, aggregation operators and
+iteration counts, shiftable windows, sub-pixel stages and all three optimisers.  Every case must be
+bit-identical (disparity, cost at the winner, float disparity, depth map).  Bayesian aggregation is
+left to its own tolerance tests."""
+import numpy as np
+import pytest
+
+import util
+from stereomatch_amd import capi, matcher, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def draw(seed):
+    r = np.random.RandomState(1000 + seed)
+    w, h = int(r.randint(2, 97)), int(r.randint(1, 41))
+    b = int(r.choice([1, 4]))
+    step = float(r.choice([1.0, 1.0, 1.0, 2.0, 0.5, 0.25]))
+    span = int(r.choice([1, 3, 7, 15, 33, 64, 100, 129]))
+    if step < 1.0:
+        span = min(span, 33)
+    if step > 1.0:
+        span = max(span, 3)
+    dmin = int(r.choice([0, 0, 0, 2, -3]))
+    seq = dict(disp_min=dmin, disp_max=dmin + span, disp_step=step,
+               disp_scale=float(r.choice([1.0, 2.0, 16.0])))
+    if r.rand() < 0.3:
+        seq.update(frame_ref=1, frame_match=0)
+    kw = dict(match_fn=int(r.choice([1, 2])), match_max=int(r.choice([1000, 50, 20, 5, 2, 1])),
+              match_interval=int(r.rand() < 0.5), match_interp=int(r.choice([1, 3])))
+    if step < 1.0 and r.rand() < 0.5:
+        kw["match_interpolated"] = 1
+    kw["aggr_fn"] = int(r.choice([1, 1, 2, 3, 4]))
+    kw["aggr_iter"] = int(r.choice([0, 1, 1, 2, 3, 5, 9]))
+    kw["aggr_window_size"] = int(r.choice([1, 3, 5, 7, 9, 11, 13, 4, 6]))
+    kw["aggr_minfilter"] = int(r.choice([0, 0, 3, 5, 9, 11, 4]))
+    kw["diff_lambda"] = float(r.choice([0.15, 0.1]))
+    kw["diff_beta"] = float(r.choice([0.5, 0.25]))
+    kw["opt_fn"] = int(r.choice([1, 1, 1, 2, 3]))
+    kw["opt_smoothness"] = float(r.choice([1.0, 5.0, 20.0, 50.0]))
+    kw["opt_grad_thresh"] = float(r.choice([5.0, 8.0]))
+    kw["opt_grad_penalty"] = float(r.choice([1.0, 2.0, 4.0]))
+    kw["opt_occlusion_cost"] = int(r.choice([20, 5, 80]))
+    kw["preproc_blur_iter"] = int(r.choice([0, 0, 0, 1, 2]))
+    if r.rand() < 0.3:
+        kw["aggr_subpixel"] = 1
+    if step < 1.0 and r.rand() < 0.4:
+        kw["aggr_collapse"] = 1
+    if r.rand() < 0.4:
+        kw["refine_subpix"] = 1
+    structured = r.rand() < 0.6
+    return w, h, b, seq, kw, structured
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_random_configuration(gpu_ctx, oracle, seed):
+    w, h, b, seq, kw, structured = draw(seed)
+    if structured:
+        ref, mtc, _ = synth.scene_pair(w, h, 16, n_bands=b, seed=77 + seed)
+    else:
+        ref, mtc = synth.noise_pair(w, h, b, seed=99 + seed)
+    p = oracle.make_params(w, h, b, **seq, **kw)
+    odisp, obest, odepth, _, ofd = oracle.compute_correspondence_f(ref, mtc, p)
+    # lines shorter than the box window are outside the reference's domain (BoxFilter.cpp:114-124
+    # reads beyond them): the library refuses, like the reference's asserts
+    refused = kw["aggr_fn"] == 1 and kw["aggr_iter"] > 0 and kw["aggr_window_size"] > min(w, h)
+    for fused in (True, False):
+        m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+        m.allow_fused = fused
+        if refused:
+            with pytest.raises(capi.SmhipError, match="BoxFilter"):
+                m.ComputeCorrespondence(ref, mtc)
+            continue
+        disp, best, depth = m.ComputeCorrespondence(ref, mtc)
+        what = "seed %d %s %s fused=%s" % (seed, seq, kw, fused)
+        assert np.array_equal(disp, odisp), what
+        util.assert_bit_equal(best, obest, what)
+        util.assert_bit_equal(np.asarray(m.m_float_disparity, np.float32), ofd, what)
+        assert np.array_equal(depth, odepth), what
