@@ -15,9 +15,11 @@ pytestmark = pytest.mark.gpu
 def draw(seed):
     r = np.random.RandomState(1000 + seed)
     w, h = int(r.randint(2, 97)), int(r.randint(1, 41))
+    if seed >= 200:                                   # larger frames: several tiles / bands per kernel
+        w, h = int(r.randint(90, 300)), int(r.randint(33, 120))
     b = int(r.choice([1, 4]))
     step = float(r.choice([1.0, 1.0, 1.0, 2.0, 0.5, 0.25]))
-    span = int(r.choice([1, 3, 7, 15, 33, 64, 100, 129]))
+    span = int(r.choice([1, 3, 7, 15, 33, 64, 100, 129, 31, 63, 127, 255, 39]))
     if step < 1.0:
         span = min(span, 33)
     if step > 1.0:
@@ -53,7 +55,7 @@ def draw(seed):
     return w, h, b, seq, kw, structured
 
 
-@pytest.mark.parametrize("seed", range(200))
+@pytest.mark.parametrize("seed", range(280))
 def test_random_configuration(gpu_ctx, oracle, seed):
     w, h, b, seq, kw, structured = draw(seed)
     if structured:
@@ -78,3 +80,26 @@ def test_random_configuration(gpu_ctx, oracle, seed):
         util.assert_bit_equal(best, obest, what)
         util.assert_bit_equal(np.asarray(m.m_float_disparity, np.float32), ofd, what)
         assert np.array_equal(depth, odepth), what
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_bayesian_configuration(gpu_ctx, oracle, seed):
+    """aggr_fn 5 over random shapes / priors, in its stated tolerance (tests/test_gpu_ops.py):
+    energies within 1e-4 * max(1, |E|) after up to 8 iterations, winners equal on >= 99 %."""
+    r = np.random.RandomState(5000 + seed)
+    w, h, b = int(r.randint(3, 80)), int(r.randint(2, 40)), int(r.choice([1, 4]))
+    span = int(r.choice([3, 7, 15, 40, 63, 64, 99, 127]))
+    seq = dict(disp_min=0, disp_max=span)
+    kw = dict(aggr_fn=5, aggr_iter=int(r.randint(1, 9)), match_fn=2, match_max=int(r.choice([12, 20, 1000])),
+              match_interval=int(r.rand() < 0.5), diff_scale_cost=float(r.choice([0.016, 0.01, 0.002])),
+              diff_mu=float(r.choice([0.5, 0.25])), diff_sigmaP=float(r.choice([0.4, 0.1, 1.0, 4.0])),
+              diff_epsP=float(r.choice([0.01, 0.05, 0.0])))
+    ref, mtc, _ = synth.scene_pair(w, h, min(span + 1, 16), n_bands=b, seed=300 + seed)
+    p = oracle.make_params(w, h, b, **seq, **kw)
+    want = oracle.aggregate(oracle.raw_costs(ref, mtc, p), p)
+    m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+    disp, _, _ = m.ComputeCorrespondence(ref, mtc)
+    got = m.download_cost()
+    err = np.abs(got.astype(np.float64) - want) / np.maximum(1.0, np.abs(want))
+    assert np.isfinite(got).all() and err.max() <= 1e-4, "seed %d %s: %.3g" % (seed, kw, err.max())
+    assert np.mean(disp == oracle.wta(want)[0]) >= 0.99
