@@ -103,3 +103,37 @@ def test_random_bayesian_configuration(gpu_ctx, oracle, seed):
     err = np.abs(got.astype(np.float64) - want) / np.maximum(1.0, np.abs(want))
     assert np.isfinite(got).all() and err.max() <= 1e-4, "seed %d %s: %.3g" % (seed, kw, err.max())
     assert np.mean(disp == oracle.wta(want)[0]) >= 0.99
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_slab_partition(gpu_ctx, oracle, seed):
+    """The multi-GPU decomposition on random shapes: the disparity range cut into random slabs,
+    smhip_fused_box_wta_keys per slab, keys merged by MIN (what the all-reduce does), decoded --
+    equal to the oracle's single-volume result."""
+    from stereomatch_amd import capi as C_, sharding
+    r = np.random.RandomState(9000 + seed)
+    w, h, b = int(r.randint(12, 200)), int(r.randint(11, 60)), int(r.choice([1, 4]))
+    D = int(r.choice([8, 16, 33, 64, 100, 128, 160, 256, 300]))
+    win = int(r.choice([3, 5, 7, 9, 11]))
+    sign = int(r.choice([0, 1]))
+    kw = dict(match_fn=int(r.choice([1, 2])), match_interval=int(r.rand() < 0.6),
+              match_max=int(r.choice([1000, 20, 2])))
+    seq = dict(disp_min=0, disp_max=D - 1)
+    if sign:
+        seq.update(frame_ref=1, frame_match=0)
+    left, right, _ = synth.scene_pair(w, h, min(D, 32), n_bands=b, seed=500 + seed)
+    p_o = oracle.make_params(w, h, b, **seq, aggr_window_size=win, **kw)
+    odisp, obest, _, _ = oracle.compute_correspondence(left, right, p_o)
+    p = C_.match_params(w, h, b, D, frame_diff_sign=-1 if sign else 1, **kw)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    n_slabs = int(r.randint(1, min(6, D // 2) + 1))
+    cuts = sorted(set([0, D] + [int(x) for x in r.randint(1, D, size=n_slabs - 1)]))
+    keys = gpu_ctx.alloc(w * h * 8)
+    merged = None
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, w * b, p, win, lo, hi - lo, keys)
+        k = gpu_ctx.download(keys, (w, h), np.int64)
+        merged = k if merged is None else np.minimum(merged, k)
+    d, c = sharding.decode_keys(merged)
+    assert np.array_equal(d.T, odisp), (seed, cuts)
+    util.assert_bit_equal(np.ascontiguousarray(c.T), obest, "best cost %s" % cuts)
