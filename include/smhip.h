@@ -39,6 +39,9 @@ extern "C" {
 #define SMHIP_EHIP     (-2)   /* HIP runtime error */
 #define SMHIP_ENOMEM   (-3)   /* device allocation failed */
 
+/* images and DSIs of more rows are refused (SMHIP_EINVAL) */
+#define SMHIP_MAX_ROWS 65535
+
 typedef struct smhip_ctx smhip_ctx;
 
 /* Replaces LineProcessStruct (CudaRawCosts.h:97-114): the parameters RawCosts derives

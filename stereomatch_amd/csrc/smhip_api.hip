@@ -92,6 +92,8 @@ int check_dsi(const void *d_cost, int w, int h, int nb, size_t row_elems)
         return fail(SMHIP_EINVAL, "row_elems %zu < width*bands %zu", row_elems, (size_t)w * nb);
     if ((size_t)w * nb > 0x7FFFFFFFul)
         return fail(SMHIP_EINVAL, "width*bands exceeds 2^31");
+    if (h > SMHIP_MAX_ROWS)                            // rows ride on gridDim.y in several kernels
+        return fail(SMHIP_EINVAL, "more than %d rows (%d) are not supported", SMHIP_MAX_ROWS, h);
     return SMHIP_OK;
 }
 
@@ -101,6 +103,8 @@ int check_params(const smhip_match_params *p, const void *d_ref, const void *d_m
         return fail(SMHIP_EINVAL, "null argument");
     if (p->width <= 0 || p->height <= 0)
         return fail(SMHIP_EINVAL, "bad image shape %dx%d", p->width, p->height);
+    if (p->height > SMHIP_MAX_ROWS)
+        return fail(SMHIP_EINVAL, "more than %d rows (%d) are not supported", SMHIP_MAX_ROWS, p->height);
     if (p->n_bands != 1 && p->n_bands != 4)   // StereoIO.cpp:76-81
         return fail(SMHIP_EINVAL, "number of bands (%d) not supported by stereo matcher", p->n_bands);
     if (pitch < (size_t)p->width * p->n_bands)

@@ -230,6 +230,11 @@ def test_error_reporting(gpu_ctx):
     with pytest.raises(capi.SmhipError) as e:                     # fused path: integer steps only
         gpu_ctx.fused_box_wta(buf, buf, 64, p, 5, buf, buf)
     assert "disp_step < 1" in str(e.value)
+    with pytest.raises(capi.SmhipError, match="rows"):            # SMHIP_MAX_ROWS: checked, nothing launched
+        gpu_ctx.wta(buf, 1, 70000, 4, 4, buf, buf)
+    p = capi.match_params(8, 70000, 1, 8)
+    with pytest.raises(capi.SmhipError, match="rows"):
+        gpu_ctx.raw_costs(buf, buf, 8, p, buf, 64)
 
 
 @pytest.mark.parametrize("h,w,d,pad", SHAPES + [(140, 30, 8, 0), (70, 21, 12, 4)])
