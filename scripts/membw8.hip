@@ -48,6 +48,9 @@ int main(int argc, char **argv)
     CK(hipMemset(a, 0, n * 4));
     double B = (double)W * H * Dp * 4;
     float tw = timeit([&] { write_A<<<H, Dp>>>(a, W, Dp, TY, 1.37f); });
+    // the same with pass A's LDS footprint (4 bytes per pixel of the row): occupancy as in the product
+    float twl = timeit([&] { write_A<<<H, Dp, (size_t)W * 4>>>(a, W, Dp, TY, 1.37f); });
+    printf("write-only with %d KB of LDS per workgroup: %.3f ms\n", W * 4 / 1024, twl);
     float tr = Dp == 256 ? timeit([&] { read_B<f4><<<(W + 3) / 4, 256>>>(a, W, H, Dp, TY, o); })
                          : timeit([&] { read_B<f2><<<(W + 3) / 4, 256>>>(a, W, H, Dp, TY, o); });
     printf("%dx%d x %d levels: write-only (pass A order) %.3f ms %5.0f GB/s (%.3f of 8 TB/s) | read-only (pass B order) %.3f ms %5.0f GB/s (%.3f)\n",
