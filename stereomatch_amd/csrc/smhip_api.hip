@@ -3,6 +3,7 @@
 #include "smhip_kernels.h"
 #include "smhip_fused.h"
 #include "smhip_fused_b.h"
+#include "smhip_fused_chunk.h"
 #include "smhip_stencil.h"
 #include "smhip_subpix.h"
 #include "smhip_stage.h"
@@ -1169,10 +1170,29 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         dim3 ga(H, Dp / tpa);
         const int nbands = p->n_bands;
         size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
+        // rows above 40 KB (4 bands: wider than 2560 pixels) are staged chunk by chunk
+        // (smhip_fused_chunk.h); SMHIP_CHUNK=1/0 forces the choice in tests
+        bool chunked = lds > 40 * 1024;
+        if (const char *e = getenv("SMHIP_CHUNK")) chunked = atoi(e) != 0;
+        const int adstep = a.dstep < 0 ? -a.dstep : a.dstep;
+        const int static_win = (window >= 3 && window <= 17 && (window & 1)) ? window : 0;
+        int chunk_steps = static_win ? (480 / static_win) * static_win : 480;
+        if (chunk_steps > W) chunk_steps = static_win ? ((W + static_win - 1) / static_win) * static_win : W;
+        long nref = (long)chunk_steps + window + 2, nmatch = nref + (long)(tpa - 1) * adstep;
+        if (nref > W) nref = W;
+        if (nmatch > W) nmatch = W;
+        if (chunked)
+            lds = (size_t)(nref + nmatch) * (nbands == 1 ? 2 : 8);
         if (lds > 150 * 1024)
-            return fail(SMHIP_EINVAL, "image width %d too large for the LDS row staging", W);
-#define LAUNCH_A3(WIN, SD, NB) smk::fused_rawbox_h_lds_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>( \
-        fa, (float *)T, tyshift, Dp, window, scale, keep_all)
+            return fail(SMHIP_EINVAL, "row staging needs %zu bytes of LDS (width %d, window %d, step %d)", lds, W,
+                        window, adstep);
+#define LAUNCH_A3(WIN, SD, NB)                                                                           \
+        do {                                                                                             \
+            if (chunked) smk::fused_rawbox_h_chunk_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>(   \
+                fa, (float *)T, tyshift, Dp, window, scale, keep_all, chunk_steps, (int)nref, (int)nmatch); \
+            else smk::fused_rawbox_h_lds_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>(             \
+                fa, (float *)T, tyshift, Dp, window, scale, keep_all);                                   \
+        } while (0)
 #define LAUNCH_A(WIN)                                                             \
         do {                                                                      \
             if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \

@@ -47,6 +47,17 @@ template <> struct RowLds<1> {
         r[i] = (uint16_t)(a.rn[ro + i] | (a.rx[ro + i] << 8));
         m[i] = (uint16_t)(a.mn[ro + i] | (a.mx[ro + i] << 8));
     }
+    // chunked staging (smhip_fused_chunk.h): nref reference and nmatch matching pixels,
+    // slot = pixel - first pixel of the chunk
+    __device__ void init2(void *base, int nref, int) { r = (uint16_t *)base; m = r + nref; }
+    __device__ void stage_r(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        r[slot] = (uint16_t)(a.rn[ro + src] | (a.rx[ro + src] << 8));
+    }
+    __device__ void stage_m(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        m[slot] = (uint16_t)(a.mn[ro + src] | (a.mx[ro + src] << 8));
+    }
     // distance between the intervals of reference pixel xr and matching pixel xm
     // (StcRawCosts.cpp:168-180; with point intervals it is |m - r|), summed over bands
     template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
@@ -66,6 +77,20 @@ template <> struct RowLds<4> {
         rx[i] = *(const uint32_t *)(a.rx + ro + 4 * (size_t)i);
         mn[i] = *(const uint32_t *)(a.mn + ro + 4 * (size_t)i);
         mx[i] = *(const uint32_t *)(a.mx + ro + 4 * (size_t)i);
+    }
+    __device__ void init2(void *base, int nref, int nmatch)
+    {
+        rn = (uint32_t *)base; rx = rn + nref; mn = rx + nref; mx = mn + nmatch;
+    }
+    __device__ void stage_r(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        rn[slot] = *(const uint32_t *)(a.rn + ro + 4 * (size_t)src);
+        rx[slot] = *(const uint32_t *)(a.rx + ro + 4 * (size_t)src);
+    }
+    __device__ void stage_m(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        mn[slot] = *(const uint32_t *)(a.mn + ro + 4 * (size_t)src);
+        mx[slot] = *(const uint32_t *)(a.mx + ro + 4 * (size_t)src);
     }
     template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
     {

@@ -220,3 +220,34 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     assert m.used_fused
     assert np.array_equal(disp, odisp)
     util.assert_bit_equal(best, obest, "best cost")
+
+
+@pytest.mark.parametrize("w,h,b,D,win,sign,step,kw", [
+    (1100, 20, 1, 64, 9, 1, 1, dict(match_fn=1, match_interval=1)),           # three chunks
+    (1000, 20, 4, 33, 9, 1, 1, dict(match_fn=2, match_max=20)),
+    (700, 20, 4, 128, 5, -1, 1, dict(match_fn=1, match_interval=1, match_max=4)),
+    (600, 20, 1, 300, 17, 1, 1, dict(match_fn=1)),                             # two level chunks of 256
+    (530, 20, 1, 40, 19, 1, 1, dict(match_fn=2)),                              # generic window
+    (481, 20, 1, 16, 3, -1, 1, dict(match_fn=1, match_max=2)),                 # chunk boundary at the last column
+    (482, 20, 1, 16, 3, 1, 1, dict(match_fn=1, match_max=2)),
+    (960, 20, 4, 60, 7, 1, 2, dict(match_fn=1, match_interval=1)),             # disp_step 2
+    (90, 20, 4, 24, 9, 1, 1, dict(match_fn=1, match_interval=1)),              # a row shorter than one chunk
+    (3000, 19, 4, 64, 9, 1, 1, dict(match_fn=1, match_interval=1)),            # chosen without the knob (48 KB row)
+])
+def test_chunked_row_staging(gpu_ctx, oracle, monkeypatch, w, h, b, D, win, sign, step, kw):
+    """Pass A with the row staged in chunks (smhip_fused_chunk.h: rows above 40 KB, e.g. 4-band 8K
+    frames; forced here through SMHIP_CHUNK) equals the oracle, and the whole-row kernel."""
+    left, right = synth.noise_pair(w, h, b, seed=400 + w)
+    fr, fm = (0, 1) if sign > 0 else (1, 0)
+    seq = dict(disp_max=(D - 1) * step, disp_step=float(step), frame_ref=fr, frame_match=fm, aggr_window_size=win)
+    odisp, obest, _, _ = oracle_run(oracle, left, right, **seq, **kw)
+    for force in ("1", "0", None):
+        if force is None:
+            monkeypatch.delenv("SMHIP_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("SMHIP_CHUNK", force)
+        m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+        disp, best, _ = m.ComputeCorrespondence(left, right)
+        assert m.used_fused
+        assert np.array_equal(disp, odisp), force
+        util.assert_bit_equal(best, obest, "best cost (SMHIP_CHUNK=%s)" % force)
