@@ -100,6 +100,8 @@ int CStereoIO::InterpretCommandLine(int argc, const char *argv[])
         return 0;
     if (frame_ref >= (int)m_fd.size() || frame_match >= (int)m_fd.size())
         throw CError("Data has not yet been read in");
+    if (evaluate_only)                                        // StereoIO.cpp:254-257: the map to evaluate
+        ReadIfThere(m_frame[frame_ref].depth_image, depth_map, false, verbose);
     if (!output_params[0]) {                                  // results/x.pgm -> results/x.txt
         strcpy(output_params, depth_map);
         strcpy(&output_params[strlen(output_params) - 3], "txt");
@@ -123,7 +125,7 @@ void CStereoIO::RunMatcher()
             allow_fused = false;
         ComputeCorrespondence();
         allow_fused = fused;
-        if (cost_map[0])
+        if (cost_map[0] && !evaluate_only)
             WriteCosts(cost_map);
     }
     if (output_params[0])

@@ -96,20 +96,32 @@ void CStereoMatcher::ComputeCorrespondence()
     disp_n = int(m_disp_step_inv * (disp_max - disp_min)) + 1;
     m_disp_step = disp_step;
     m_disp_n = disp_n;
-    if (verbose >= eVerboseProgress)
-        fprintf(stderr, "\nComputing correspondence between frames %d and %d\n"
-                        "disp_n = %d, disp_min = %d, m_disp_num = %d, m_disp_den = %d, disp_scale = %g\n",
-                frame_ref, frame_match, disp_n, disp_min, m_disp_num, m_disp_den, disp_scale);
-    if (evaluate_only)
-        throw CError("ComputeCorrespondence: evaluate_only is not part of the device hot path");
+    if (verbose >= eVerboseProgress) {
+        if (evaluate_only)
+            fprintf(stderr, "\nEvaluating existing depth map\n");
+        else
+            fprintf(stderr, "\nComputing correspondence between frames %d and %d\n"
+                            "disp_n = %d, disp_min = %d, m_disp_num = %d, m_disp_den = %d, disp_scale = %g\n",
+                    frame_ref, frame_match, disp_n, disp_min, m_disp_num, m_disp_den, disp_scale);
+    }
 
     m_reference = ref;
     m_matching = mat;
     CShape shD(sh0.width, sh0.height, 1);
     CByteImage &depth_image = m_frame[frame_ref].depth_image;
     if (depth_image.Shape() != shD)
-        depth_image.ReAllocate(shD);
+        depth_image.ReAllocate(shD);                          // (zeros; a depth map read for evaluate_only is kept)
     m_float_disparity.ReAllocate(shD);
+    {   // m_float_disparity from the depth map on file (StereoMatcher.cpp:117): what evaluate_only evaluates
+        float d_scale = 1.0f / disp_scale, d_offset = (float)disp_min;
+        bool d_so = (d_scale != 1.0f) || (d_offset != 0.0f);
+        for (int y = 0; y < shD.height; y++) {
+            const uchar *src = depth_image.Row(y);
+            float *dst = m_float_disparity.Row(y);
+            for (int x = 0; x < shD.width; x++)
+                dst[x] = d_so ? src[x] * d_scale + d_offset : (float)src[x];
+        }
+    }
     // ground truth in disparity units, zeros when there is none (StereoMatcher.cpp:121-130)
     m_true_disparity.ReAllocate(shD);
     const CByteImage &truth_image = m_frame[frame_ref].truth_image;
@@ -125,6 +137,17 @@ void CStereoMatcher::ComputeCorrespondence()
     }
     m_disparity.ReAllocate(shD);
     m_best_cost.ReAllocate(shD);
+    if (evaluate_only) {
+        // StereoMatcher.cpp:132-152: integer levels k = (d - disp_min) / disp_step from the float
+        // disparities (Convert.cpp float -> int: truncation), and nothing of the matcher runs
+        for (int y = 0; y < shD.height; y++) {
+            const float *src = m_float_disparity.Row(y);
+            int *dst = m_disparity.Row(y);
+            for (int x = 0; x < shD.width; x++)
+                dst[x] = (int)(src[x] * m_disp_step_inv + (-(float)disp_min * disp_step));
+        }
+        return;
+    }
     if (m_disp_n < 2)
         throw CError("ComputeCorrespondence: too few disparity levels (%d)", m_disp_n);
 
