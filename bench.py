@@ -193,6 +193,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(np, left, right, args, Dg, win)
             out["cpu_baseline_all_cores"] = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
+            if "extra" in out:
+                out["extra"]["config4_cpu"] = cpu_config4(np, synth)
         print(json.dumps(out), flush=True)
 
     if world > 1:
@@ -282,6 +284,23 @@ def cpu_baseline(np, left, right, args, D, win, openmp=False):
                           rows, left.shape[0], w, left.shape[0], D, dt,
                           " -fopenmp, rows / column blocks over %d threads" % cores if openmp
                           else ", single thread like the reference")}
+
+
+def cpu_config4(np, synth):
+    """CPU side of config 4 (size-normalised, on a sub-volume the CPU path can hold): one
+    binomial and one diffusion iteration of the oracle on 3840x2160 x 4 levels, single thread."""
+    from oracle import oracle as O
+    W, H, D = 3840, 2160, 4
+    left, right, _ = synth.scene_pair(W, H, 256)
+    p = O.make_params(W, H, 1, disp_min=0, disp_max=D - 1, match_fn=1, match_interval=1)
+    c = O.raw_costs(left, right, p)
+    res = {"sub_volume": "3840x2160 x %d levels (of 512), oracle/sm_oracle.c, one thread" % D}
+    for name, fn in (("binomial", lambda: O.convolve_14641(c)), ("diffusion", lambda: O.diffusion_iter(c, 0.15, 0.0, None))):
+        t0 = time.perf_counter()
+        fn()
+        dt = time.perf_counter() - t0
+        res[name + "_G_voxel_iterations_per_s"] = round(W * H * D / dt / 1e9, 4)
+    return res
 
 
 if __name__ == "__main__":
