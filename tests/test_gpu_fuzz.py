@@ -3,6 +3,8 @@ band counts, disparity ranges / steps / directions, matching costs, aggregation 
 iteration counts, shiftable windows, sub-pixel stages and all three optimisers.  Every case must be
 bit-identical (disparity, cost at the winner, float disparity, depth map).  Bayesian aggregation is
 left to its own tolerance tests."""
+import os
+
 import numpy as np
 import pytest
 
@@ -15,7 +17,7 @@ pytestmark = pytest.mark.gpu
 def draw(seed):
     r = np.random.RandomState(1000 + seed)
     w, h = int(r.randint(2, 97)), int(r.randint(1, 41))
-    if seed >= 200:                                   # larger frames: several tiles / bands per kernel
+    if seed >= 200 and seed % 3 != 0:                 # larger frames: several tiles / bands per kernel
         w, h = int(r.randint(90, 300)), int(r.randint(33, 120))
     b = int(r.choice([1, 4]))
     step = float(r.choice([1.0, 1.0, 1.0, 2.0, 0.5, 0.25]))
@@ -55,7 +57,7 @@ def draw(seed):
     return w, h, b, seq, kw, structured
 
 
-@pytest.mark.parametrize("seed", range(280))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMHIP_FUZZ_N", "280"))))   # more on demand
 def test_random_configuration(gpu_ctx, oracle, seed):
     w, h, b, seq, kw, structured = draw(seed)
     if structured:
