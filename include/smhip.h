@@ -142,6 +142,14 @@ int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_
                         int n_bands, size_t row_elems, float scale_cost, float mu, float sigmaP,
                         float epsP, int iter);
 
+/* The aggr_iter loop of AggrBayesian as one call (StcAggregate.cpp:265-343 with :320-330): the same
+ * values as n_iter calls of smhip_bayesian_iter, but between iterations only the smoothed energies
+ * are stored (12 instead of 20 bytes per voxel and iteration).  *result_in_b = 1 when the energies
+ * E end up in d_cost2 instead of d_cost (the host swaps m_cost / m_cost2, as after smhip_diffusion_run). */
+int smhip_bayesian_run(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h,
+                       int n_bands, size_t row_elems, float scale_cost, float mu, float sigmaP,
+                       float epsP, int n_iter, int *result_in_b);
+
 /* n_iter iterations of AggrDiffusion / of the binomial filter (the aggr_iter loop of
  * StcAggregate.cpp:265-343) with up to four iterations per pass over the DSI (temporal blocking,
  * csrc/smhip_multi.h); bit-identical to n_iter single calls.  d_a holds the input, d_a and d_b

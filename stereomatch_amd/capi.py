@@ -24,7 +24,7 @@ SYMBOLS = [
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
-    "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp",
+    "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run",
 ]
 
 
@@ -121,6 +121,7 @@ def load():
     L.smhip_convolve_14641_to.argtypes = [vp, vp, vp, ci, ci, ci, sz]
     L.smhip_diffusion_iter.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf]
     L.smhip_bayesian_iter.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, cf, cf, ci]
+    L.smhip_bayesian_run.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, cf, cf, ci, C.POINTER(ci)]
     L.smhip_pad_costs.argtypes = [vp, vp, sz, pp]
     L.smhip_wta.argtypes = [vp, vp, ci, ci, ci, sz, vp, vp]
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
@@ -277,6 +278,14 @@ class Context:
         """One AggrBayesian iteration (StcDiffusion.cpp:139-308), E in place; tolerance mode."""
         self._chk(self.L.smhip_bayesian_iter(self.h, _ptr(d_cost), _ptr(d_cost2), _ptr(d_cost0), w, h,
                                              nb, row_elems, scale_cost, mu, sigma_p, eps_p, it))
+
+    def bayesian_run(self, d_cost, d_cost2, d_cost0, w, h, nb, row_elems, scale_cost, mu, sigma_p, eps_p,
+                     n_iter):
+        """n_iter AggrBayesian iterations in one call; returns True when E is in d_cost2."""
+        flag = C.c_int()
+        self._chk(self.L.smhip_bayesian_run(self.h, _ptr(d_cost), _ptr(d_cost2), _ptr(d_cost0), w, h, nb,
+                                            row_elems, scale_cost, mu, sigma_p, eps_p, n_iter, C.byref(flag)))
+        return bool(flag.value)
 
     def diffusion_run(self, d_a, d_b, d_cost0, w, h, nb, row_elems, lam, beta, n_iter):
         """n_iter iterations, up to four per pass; returns True when the result is in d_b."""

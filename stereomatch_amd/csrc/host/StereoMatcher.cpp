@@ -366,10 +366,10 @@ void CStereoMatcher::Aggregate()
             DeviceBuffer(B_COST2, bytes);
             DeviceBuffer(B_COST0, bytes);
         }
-        for (int iter = 0; iter < aggr_iter; iter++)
-            Check(smhip_bayesian_iter(m_ctx, (float *)m_dev[B_COST], (float *)m_dev[B_COST2],
-                                      (float *)m_dev[B_COST0], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
-                                      diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP, iter));
+        if (aggr_iter > 0)
+            Check(smhip_bayesian_run(m_ctx, (float *)m_dev[B_COST], (float *)m_dev[B_COST2],
+                                     (float *)m_dev[B_COST0], m_mp.width, m_mp.height, m_disp_n, m_row_elems,
+                                     diff_scale_cost, diff_mu, diff_sigmaP, diff_epsP, aggr_iter, &in_b));
         break;
     default:
         throw CError("CStereoMatcher::Aggregate(): unknown aggregation function");

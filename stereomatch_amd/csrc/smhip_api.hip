@@ -994,8 +994,12 @@ int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
     return SMHIP_OK;
 }
 
-int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h, int nb,
-                        size_t row_elems, float scale_cost, float mu, float sigmaP, float epsP, int iter)
+namespace {
+
+// w(d, d') = rhoP(d - d') / row sum, on the host as the reference computes it (:209-222), then the
+// band (w - e_d) and e_d = epsP / s_d the kernel sums (see smhip_bayes.h); cached per context
+int bayes_prepare(smhip_ctx *ctx, const float *d_cost, const float *d_cost2, const float *d_cost0, int w, int h,
+                  int nb, size_t row_elems, float sigmaP, float epsP)
 {
     int rc = check_ctx(ctx);
     if (rc) return rc;
@@ -1006,64 +1010,113 @@ int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_
     if (nb > SMHIP_BAYES_MAX_LEVELS)                 // the reference asserts m_disp_n < 100 (:200-202)
         return fail(SMHIP_EINVAL, "Bayesian diffusion: at most %d disparity levels (%d given)",
                     SMHIP_BAYES_MAX_LEVELS, nb);
-    if (h > 65535)
-        return fail(SMHIP_EINVAL, "Bayesian diffusion: at most 65535 rows");
-    if (iter < 0)
-        return fail(SMHIP_EINVAL, "negative iteration index");
     static_assert(SMHIP_BAYES_MAX_LEVELS == smk::BAYES_MAXD, "header and kernel limits differ");
     const int DP = nb <= 64 ? 64 : 128;
     const size_t band_cap = (size_t)(2 * SMHIP_BAYES_MAX_LEVELS - 1) * SMHIP_BAYES_MAX_LEVELS;
-    if (ctx->bayes_n != nb || ctx->bayes_sigma != sigmaP || ctx->bayes_eps != epsP) {
-        // w(d, d') = rhoP(d - d') / row sum, on the host as the reference computes it (:209-222),
-        // then the band (w - e_d) and e_d = epsP / s_d the kernel sums (see smhip_bayes.h)
-        const size_t cap = (band_cap + SMHIP_BAYES_MAX_LEVELS) * sizeof(double);
-        if (!ctx->bayes_wh && !(ctx->bayes_wh = (double *)malloc(cap)))
-            return fail(SMHIP_ENOMEM, "out of host memory");
-        if (!ctx->bayes_w)
-            HIP_TRY(hipMalloc((void **)&ctx->bayes_w, cap));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));  // an earlier iteration may still read the old ones
-        int B = 0;
-        for (int d = 1; d < nb; d++) {
-            float diff = d;
-            float r = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP);
-            if (!(r == epsP))
-                B = d;
-        }
-        double *band = ctx->bayes_wh, *ed = band + band_cap, row[SMHIP_BAYES_MAX_LEVELS];
-        memset(band, 0, cap);
-        for (int d = 0; d < nb; d++) {
-            float s = 0.0;
-            for (int d2 = 0; d2 < nb; d2++) {
-                float diff = (d - d2);
-                s += (row[d2] = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP));
-            }
-            for (int d2 = 0; d2 < nb; d2++)
-                row[d2] /= s;
-            double e = B < nb - 1 ? (double)epsP : 0.0;   // the full product has no constant part
-            e /= s;
-            ed[d] = e;
-            for (int k = -B; k <= B; k++)
-                if (d + k >= 0 && d + k < nb)
-                    band[(size_t)(k + B) * DP + d] = row[d + k] - e;
-        }
-        HIP_TRY(hipMemcpyAsync(ctx->bayes_w, band, cap, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->bayes_n = nb;
-        ctx->bayes_sigma = sigmaP;
-        ctx->bayes_eps = epsP;
-        ctx->bayes_band = B;
+    if (ctx->bayes_n == nb && ctx->bayes_sigma == sigmaP && ctx->bayes_eps == epsP)
+        return SMHIP_OK;
+    const size_t cap = (band_cap + SMHIP_BAYES_MAX_LEVELS) * sizeof(double);
+    if (!ctx->bayes_wh && !(ctx->bayes_wh = (double *)malloc(cap)))
+        return fail(SMHIP_ENOMEM, "out of host memory");
+    if (!ctx->bayes_w)
+        HIP_TRY(hipMalloc((void **)&ctx->bayes_w, cap));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));      // an earlier iteration may still read the old ones
+    int B = 0;
+    for (int d = 1; d < nb; d++) {
+        float diff = d;
+        float r = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP);
+        if (!(r == epsP))
+            B = d;
     }
+    double *band = ctx->bayes_wh, *ed = band + band_cap, row[SMHIP_BAYES_MAX_LEVELS];
+    memset(band, 0, cap);
+    for (int d = 0; d < nb; d++) {
+        float s = 0.0;
+        for (int d2 = 0; d2 < nb; d2++) {
+            float diff = (d - d2);
+            s += (row[d2] = ((1 - epsP) * expf(-diff * diff / (2 * sigmaP * sigmaP)) + epsP));
+        }
+        for (int d2 = 0; d2 < nb; d2++)
+            row[d2] /= s;
+        double e = B < nb - 1 ? (double)epsP : 0.0;   // the full product has no constant part
+        e /= s;
+        ed[d] = e;
+        for (int k = -B; k <= B; k++)
+            if (d + k >= 0 && d + k < nb)
+                band[(size_t)(k + B) * DP + d] = row[d + k] - e;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->bayes_w, band, cap, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->bayes_n = nb;
+    ctx->bayes_sigma = sigmaP;
+    ctx->bayes_eps = epsP;
+    ctx->bayes_band = B;
+    return SMHIP_OK;
+}
+
+// steps 1-3 of one iteration: E (or, fused, E0 + mu * 5-point(es_in)) -> es_out
+void bayes_smooth(smhip_ctx *ctx, float *e, float *es_out, float *e0_init, float scale_cost, const float *es_in,
+                  float *e0, float mu, int w, int h, int nb, size_t row_elems)
+{
+    const size_t band_cap = (size_t)(2 * SMHIP_BAYES_MAX_LEVELS - 1) * SMHIP_BAYES_MAX_LEVELS;
     long n_pix = (long)w * h;
     unsigned blocks = (unsigned)((n_pix + 3) / 4 < 4096 ? (n_pix + 3) / 4 : 4096);
-    float *e0 = iter == 0 ? d_cost0 : nullptr;
-#define LAUNCH_BS(S, HB) smk::bayes_smooth_kernel<S, HB><<<blocks, 256, 0, ctx->stream>>>( \
-        d_cost, d_cost2, e0, scale_cost, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h, nb, row_elems)
     const bool narrow = ctx->bayes_band <= 6;        // sigmaP up to about 0.5: the band lives in registers
-    if (DP == 64) { if (narrow) LAUNCH_BS(1, 6); else LAUNCH_BS(1, 0); }
-    else          { if (narrow) LAUNCH_BS(2, 6); else LAUNCH_BS(2, 0); }
+    const bool two = nb > 64;
+#define LAUNCH_BS(S, HB)                                                                                    \
+    do {                                                                                                    \
+        if (es_in) smk::bayes_smooth_kernel<S, HB, true><<<blocks, 256, 0, ctx->stream>>>(                  \
+            nullptr, es_out, e0, 0.0f, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h, nb,    \
+            row_elems, es_in, mu);                                                                          \
+        else smk::bayes_smooth_kernel<S, HB, false><<<blocks, 256, 0, ctx->stream>>>(                       \
+            e, es_out, e0_init, scale_cost, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h,   \
+            nb, row_elems);                                                                                 \
+    } while (0)
+    if (!two) { if (narrow) LAUNCH_BS(1, 6); else LAUNCH_BS(1, 0); }
+    else      { if (narrow) LAUNCH_BS(2, 6); else LAUNCH_BS(2, 0); }
 #undef LAUNCH_BS
+}
+
+}  // namespace
+
+int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h, int nb,
+                        size_t row_elems, float scale_cost, float mu, float sigmaP, float epsP, int iter)
+{
+    if (iter < 0)
+        return fail(SMHIP_EINVAL, "negative iteration index");
+    int rc = bayes_prepare(ctx, d_cost, d_cost2, d_cost0, w, h, nb, row_elems, sigmaP, epsP);
+    if (rc) return rc;
+    bayes_smooth(ctx, d_cost, d_cost2, iter == 0 ? d_cost0 : nullptr, scale_cost, nullptr, nullptr, mu, w, h, nb,
+                 row_elems);
     dim3 ge((w * nb + 255) / 256, h);
     smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(d_cost, d_cost2, d_cost0, w, nb, h, row_elems, mu);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_bayesian_run(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h, int nb,
+                       size_t row_elems, float scale_cost, float mu, float sigmaP, float epsP, int n_iter,
+                       int *result_in_b)
+{
+    if (n_iter < 0 || !result_in_b)
+        return fail(SMHIP_EINVAL, "Bayesian diffusion: bad iteration count / result flag");
+    int rc = bayes_prepare(ctx, d_cost, d_cost2, d_cost0, w, h, nb, row_elems, sigmaP, epsP);
+    if (rc) return rc;
+    *result_in_b = 0;
+    if (n_iter == 0)
+        return SMHIP_OK;
+    // iteration 0: E = scale * cost (kept as E0), Es -> d_cost2.  Iteration k: E is formed inside the
+    // smoothing kernel from the previous Es, which ping-pongs between d_cost2 and d_cost (E itself is not
+    // needed between iterations).  The last step materialises E in the buffer that does not hold Es.
+    bayes_smooth(ctx, d_cost, d_cost2, d_cost0, scale_cost, nullptr, nullptr, mu, w, h, nb, row_elems);
+    float *es = d_cost2, *other = d_cost;
+    for (int it = 1; it < n_iter; it++) {
+        bayes_smooth(ctx, nullptr, other, nullptr, 0.0f, es, d_cost0, mu, w, h, nb, row_elems);
+        float *t = es; es = other; other = t;
+    }
+    dim3 ge((w * nb + 255) / 256, h);
+    smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(other, es, d_cost0, w, nb, h, row_elems, mu);
+    *result_in_b = (other == d_cost2);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

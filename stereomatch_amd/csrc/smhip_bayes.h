@@ -72,12 +72,17 @@ constexpr int BAYES_LINE = 3 * BAYES_MAXD;
 // ed = e_d per level.  E0 != nullptr (first iteration): E *= scale first, and E0 = E (:182-191).
 // HB > 0: bands up to half-width HB are held in registers for the whole kernel (the weights
 // depend on the level only); HB = 0: any band, weights read in the loop.
-template <int SLOTS, int HB>
+// FUSED: E is not read but formed on the fly from the previous iteration's smoothed energies
+// EsIn, E = E0 + mu * (Es + left + right + up + down) -- step 4 of that iteration, the same float
+// expression as bayes_update_kernel -- so a run of iterations moves 12 instead of 20 bytes per voxel
+// and iteration (smhip_bayesian_run).
+template <int SLOTS, int HB, bool FUSED = false>
 __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E, float *__restrict__ Es,
                                                            float *__restrict__ E0, float scale,
                                                            const double *__restrict__ wb,
                                                            const double *__restrict__ ed, int B, int W, int H,
-                                                           int D, size_t row_elems)
+                                                           int D, size_t row_elems,
+                                                           const float *__restrict__ EsIn = nullptr, float mu = 0.0f)
 {
     constexpr int DP = 64 * SLOTS;
     __shared__ double line[4][BAYES_LINE];
@@ -108,8 +113,23 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
                 break;
         }
         const size_t o = (size_t)y * row_elems + (size_t)x * D;
-        float eA = inA ? E[o + dA] : 0.0f, eB = inB ? E[o + dB] : 0.0f;
-        if (E0) {
+        float eA = 0.0f, eB = 0.0f;
+        if constexpr (FUSED) {
+            const long lf = x > 0 ? -(long)D : 0, rt = x < W - 1 ? (long)D : 0;
+            const long up = y > 0 ? -(long)row_elems : 0, dn = y < H - 1 ? (long)row_elems : 0;
+            if (inA) {
+                const float *s = EsIn + o + dA;
+                eA = E0[o + dA] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
+            }
+            if (inB) {
+                const float *s = EsIn + o + dB;
+                eB = E0[o + dB] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
+            }
+        } else {
+            eA = inA ? E[o + dA] : 0.0f;
+            eB = inB ? E[o + dB] : 0.0f;
+        }
+        if (!FUSED && E0) {
             eA = eA * scale + 0.0f;
             eB = eB * scale + 0.0f;
             if (inA) E[o + dA] = E0[o + dA] = eA;

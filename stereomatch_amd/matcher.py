@@ -205,9 +205,11 @@ class StereoMatcher(StereoParameters):
             if self.aggr_iter > 0:
                 es = self._buf("cost2", nbytes)
                 e0 = self._buf("cost0", nbytes)
-                for it in range(self.aggr_iter):
-                    c.bayesian_iter(self.d_cost, es, e0, w, h, nb, re, self.diff_scale_cost, self.diff_mu,
-                                    self.diff_sigmaP, self.diff_epsP, it)
+                in_b = c.bayesian_run(self.d_cost, es, e0, w, h, nb, re, self.diff_scale_cost, self.diff_mu,
+                                      self.diff_sigmaP, self.diff_epsP, self.aggr_iter)
+                if in_b:
+                    self._bufs["cost"], self._bufs["cost2"] = es, self.d_cost
+                    self.d_cost = es
         else:
             raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
         if self.aggr_minfilter > 1 and self._min_wta_fusable():          # :351-365 + OptWTA, no DSI write

@@ -471,3 +471,26 @@ def test_opt_dp(gpu_ctx, oracle, h, w, d, b, par):
     assert np.array_equal(got, want), "%d of %d pixels differ" % (np.sum(got != want), got.size)
     gb = gpu_ctx.download(best, (h, w), np.float32)
     util.assert_bit_equal(gb, np.take_along_axis(c, want[:, :, None], 2)[:, :, 0], "cost at the chosen level")
+
+
+@pytest.mark.parametrize("h,w,d,pad", [(6, 20, 7, 0), (5, 9, 64, 3), (4, 11, 99, 0), (3, 7, 128, 0), (1, 9, 16, 0),
+                                       (7, 1, 5, 0), (40, 70, 33, 1)])
+@pytest.mark.parametrize("n_iter", [0, 1, 2, 3, 6])
+def test_bayesian_run_equals_iterations(gpu_ctx, h, w, d, pad, n_iter):
+    """smhip_bayesian_run (energies formed inside the smoothing kernel between iterations) gives the
+    bits of n_iter calls of smhip_bayesian_iter: the same float operations, fewer passes."""
+    c = util.rand_dsi(h, w, d, 70 + d, "float") * np.float32(0.4)
+    re = w * d + pad
+    host = np.full((h, re), np.float32(-7.0))
+    host[:, :w * d] = c.reshape(h, w * d)
+    a, a2, a0 = up(gpu_ctx, host), gpu_ctx.alloc(h * re * 4), gpu_ctx.alloc(h * re * 4)
+    for it in range(n_iter):
+        gpu_ctx.bayesian_iter(a, a2, a0, w, h, d, re, 0.016, 0.5, 0.4, 0.01, it)
+    want = gpu_ctx.download(a, (h, re), np.float32)
+    b, b2, b0 = up(gpu_ctx, host), up(gpu_ctx, np.zeros((h, re), np.float32)), gpu_ctx.alloc(h * re * 4)
+    in_b = gpu_ctx.bayesian_run(b, b2, b0, w, h, d, re, 0.016, 0.5, 0.4, 0.01, n_iter)
+    assert in_b == (n_iter > 0 and n_iter % 2 == 0)
+    got = gpu_ctx.download(b2 if in_b else b, (h, re), np.float32)
+    util.assert_bit_equal(got[:, :w * d], want[:, :w * d], "energies after %d iterations" % n_iter)
+    if pad and not in_b:
+        assert np.all(got[:, w * d:] == np.float32(-7.0)), "row padding was overwritten"
