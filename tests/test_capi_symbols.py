@@ -32,3 +32,22 @@ def test_match_outside_needs_no_gpu():
     assert L.smhip_match_outside(ctypes.byref(p)) == 4 * 255 * 255      # StcRawCosts.cpp:365-367
     p = capi.match_params(384, 288, 4, 16, match_fn=1, match_max=20)
     assert L.smhip_match_outside(ctypes.byref(p)) == 20
+
+
+def test_header_is_plain_c99():
+    """include/smhip.h is what a cgo / JNI / ctypes binding reads: it has to be C, not C++."""
+    import subprocess
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only",
+                        "-x", "c", os.path.join(ROOT, "include", "smhip.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_c_demo_links(tmp_path):
+    """examples/c_abi_demo.c (a C99 caller) compiles and links against the library without warnings."""
+    import subprocess
+    lib_dir = os.path.dirname(capi.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", lib_dir, "-lsmhip",
+                        "-Wl,-rpath," + lib_dir, "-o", str(tmp_path / "c_abi_demo")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
