@@ -330,6 +330,50 @@ def evaluate(fdisp, truth, ref, p, verbose_summary=True, **kw):
     return res
 
 
+class Predict(C.Structure):
+    """smo_predict with the defaults of StereoParameters.cpp:104-113."""
+    _fields_ = [("predict_type", C.c_int), ("lin_interp", C.c_int), ("disp_gap", C.c_float),
+                ("predict_diff", C.c_int), ("empty_color", C.c_int), ("partial_shuffle", C.c_float)]
+
+
+def prediction_error(ref, frame, fdisp, shift, **kw):
+    """One frame of ComputePredictionErrors: returns (rms over visible pixels, visible fraction,
+    re-projected image [H, W, B])."""
+    q = Predict(predict_type=1, lin_interp=1, disp_gap=2.0, predict_diff=0, empty_color=0x00ffc0ff,
+                partial_shuffle=0.0)
+    for k, v in kw.items():
+        if not hasattr(q, k):
+            raise KeyError(k)
+        setattr(q, k, v)
+    ref, frame = _img(ref), _img(frame)
+    h, w, b = ref.shape
+    assert frame.shape == ref.shape and b in (1, 4)
+    fd = np.ascontiguousarray(fdisp, np.float32).reshape(h, w)
+    out = np.empty((h, w, b), np.uint8)
+    vis = C.c_float()
+    L = lib()
+    L.smo_prediction_error.restype = C.c_float
+    L.smo_prediction_error.argtypes = [C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_int,
+                                       C.POINTER(C.c_float), C.c_float, C.POINTER(Predict),
+                                       C.POINTER(C.c_uint8), C.POINTER(C.c_float)]
+    rms = L.smo_prediction_error(_u8(ref), _u8(frame), w, h, b, _fp(fd), shift, C.byref(q), _u8(out),
+                                 C.byref(vis))
+    return float(rms), float(vis.value), out
+
+
+def predict_slot(f, frame_ref, frame_match):
+    """Which predict_err_* output frame f feeds (StcEvaluate.cpp:742-756), or None."""
+    if 2 * f == 4 * frame_ref - 2 * frame_match or 2 * f == 3 * frame_ref - frame_match:
+        return "near"
+    if 2 * f == frame_ref + frame_match:
+        return "middle"
+    if 2 * f == 2 * frame_match:
+        return "match"
+    if 2 * f == -frame_ref + 3 * frame_match or 2 * f == -2 * frame_ref + 4 * frame_match:
+        return "far"
+    return None
+
+
 def opt_so(cost, ref, p):
     """OptSO on a DSI [H, W, D]: returns the disparity map."""
     c = np.ascontiguousarray(cost, np.float32)

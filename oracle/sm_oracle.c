@@ -970,6 +970,227 @@ void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, 
 }
 
 /* ------------------------------------------------------------------------- */
+/* prediction (re-projection) error of one frame: StcEvaluate.cpp:588-758,      */
+/* ForwardWarp / InverseWarp of Warp1D.cpp:25-257, Min/MaxFilter<uchar> 3x3     */
+/* (MinFilter.cpp:122-202).  No output of the reference pins these numbers:     */
+/* "parity unpinned" (tests check known answers and the host driver against it) */
+
+/* draw_intensity_line (Warp1D.cpp:25-56), uchar, all bands of a pixel */
+static void draw_line_u8n(const uint8_t *s1, const uint8_t *s2, uint8_t *dst, float x1, float x2,
+                          int w, int nb)
+{
+    if (x2 < x1)
+        return;
+    int i0 = imax(0, SMO_ROUND(x1));
+    int i1 = imin(w - 1, SMO_ROUND(x2));
+    float iden = 1.0 / (x2 - x1 + (x2 == x1));
+    for (int i = i0; i <= i1; i++) {
+        float f = (i - x1) * iden;
+        for (int b = 0; b < nb; b++) {
+            float v1 = s1[b], v2 = s2[b];
+            float v = v1 + f * (v2 - v1);
+            float r = v + 0.5f;
+            r = r > 0 ? r : 0;
+            r = r < 255 ? r : 255;
+            dst[(size_t)i * nb + b] = (uint8_t)r;
+        }
+    }
+}
+
+/* ForwardWarp<uchar> (Warp1D.cpp:58-128), one row of an nb-band image */
+static void forward_warp_row_u8n(const uint8_t *ps, uint8_t *pd, const float *dp, int w, int nb,
+                                 float d_scale, int line_interpolate, float disp_gap)
+{
+    int xstart = d_scale > 0 ? 0 : w - 1, xend = d_scale > 0 ? w : -1, xincr = d_scale > 0 ? 1 : -1;
+    for (int x = xstart; x != xend; x += xincr) {
+        int x2 = x + xincr;
+        int draw = 0;
+        if (line_interpolate && x2 != xend)
+            draw = fabsf(dp[x] - dp[x2]) < disp_gap;
+        float d = d_scale * dp[x];
+        if (draw) {
+            float d2 = d_scale * dp[x2];
+            if (xincr > 0)
+                draw_line_u8n(&ps[(size_t)x * nb], &ps[(size_t)x2 * nb], pd, x - d, x2 - d2, w, nb);
+            else                                     /* (x2 - d, x - d2) as written at :115-117 */
+                draw_line_u8n(&ps[(size_t)x2 * nb], &ps[(size_t)x * nb], pd, x2 - d, x - d2, w, nb);
+            continue;
+        }
+        int xx = x - SMO_ROUND(d);
+        if (xx >= 0 && xx < w)
+            memcpy(&pd[(size_t)xx * nb], &ps[(size_t)x * nb], nb);
+    }
+}
+
+/* InverseWarpLine (Warp1D.cpp:144-194) */
+static void inverse_warp_line(const float *src, float *dst, const float *disp, int w, int nb, int order,
+                              const float *fwd_disp, float disp_gap)
+{
+    for (int x = 0; x < w; x++, dst += nb) {
+        float d = disp[x];
+        float y = x - d;
+        if (y < 0.0 || y > w - 1)
+            continue;
+        int xx = (int)y;
+        if (fwd_disp && disp_gap && fabs(d - fwd_disp[xx]) >= disp_gap)
+            continue;
+        const float *ps0 = &src[(size_t)xx * nb];
+        if (order == 0 || xx == y) {
+            memcpy(dst, ps0, nb * sizeof(float));
+        } else if (order == 1 || xx - 1 < 0 || xx + 2 > w - 1) {
+            float f = y - xx;
+            const float *ps1 = &ps0[nb];
+            for (int b = 0; b < nb; b++)
+                dst[b] = ps0[b] + f * (ps1[b] - ps0[b]);
+        } else {                                     /* order 3 */
+            float f = y - xx;
+            const float *psp = &ps0[-nb], *ps1 = &ps0[nb], *ps2 = &ps0[2 * nb];
+            for (int b = 0; b < nb; b++)
+                dst[b] = cubic_interp(f, psp[b], ps0[b], ps1[b], ps2[b]);
+        }
+    }
+}
+
+/* 3x3 minimum (do_max = 0) or maximum of every band, replicate border: what MinMaxFilter
+ * (MinFilter.cpp:122-202) computes for xWidth = yWidth = 3 (pl = -2, pr = 1: cells x-1 .. x+1) */
+static void minmax3_u8(const uint8_t *src, uint8_t *dst, int w, int h, int nb, int do_max)
+{
+    size_t row = (size_t)w * nb;
+    uint8_t *tmp = malloc(row * h);
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int b = 0; b < nb; b++) {
+                const uint8_t *r = src + y * row;
+                uint8_t a = r[(size_t)clampi(x - 1, w) * nb + b], c = r[(size_t)x * nb + b],
+                        e = r[(size_t)clampi(x + 1, w) * nb + b];
+                uint8_t m = do_max ? (a > c ? a : c) : (a < c ? a : c);
+                tmp[y * row + (size_t)x * nb + b] = do_max ? (m > e ? m : e) : (m < e ? m : e);
+            }
+    for (int y = 0; y < h; y++)
+        for (size_t i = 0; i < row; i++) {
+            uint8_t a = tmp[clampi(y - 1, h) * row + i], c = tmp[y * row + i], e = tmp[clampi(y + 1, h) * row + i];
+            uint8_t m = do_max ? (a > c ? a : c) : (a < c ? a : c);
+            dst[y * row + i] = do_max ? (m > e ? m : e) : (m < e ? m : e);
+        }
+    free(tmp);
+}
+
+/* PartialShuffle (StcEvaluate.cpp:588-614) */
+static void partial_shuffle(const uint8_t *img, uint8_t *mn, uint8_t *mx, int w, int h, int nb, float amt)
+{
+    minmax3_u8(img, mn, w, h, nb, 0);
+    minmax3_u8(img, mx, w, h, nb, 1);
+    size_t n = (size_t)w * h * nb;
+    for (size_t i = 0; i < n; i++) {
+        mn[i] = (int)(img[i] + amt * (mn[i] - (int)img[i]));              /* round down */
+        mx[i] = (int)(img[i] + amt * (mx[i] - (int)img[i]) + 0.99f);      /* round up */
+    }
+}
+
+/* ComputePredictionError (StcEvaluate.cpp:615-690); `predicted` is rewritten when predict_diff != 0 */
+static float prediction_error(uint8_t *predicted, const uint8_t *original, int w, int h, int nB,
+                              const smo_predict *q, float *fraction_visible)
+{
+    int nC = nB - (nB > 1);
+    float sum2 = 0.0;
+    int visible = 0, total = w * h;
+    size_t n = (size_t)w * h * nB;
+    int shuffle = q->partial_shuffle > 0.0f;
+    uint8_t *pn = NULL, *px = NULL, *on = NULL, *ox = NULL;
+    if (shuffle) {
+        pn = malloc(n); px = malloc(n); on = malloc(n); ox = malloc(n);
+        partial_shuffle(predicted, pn, px, w, h, nB, q->partial_shuffle);
+        partial_shuffle(original, on, ox, w, h, nB, q->partial_shuffle);
+    }
+    for (int y = 0; y < h; y++) {
+        uint8_t *p = predicted + (size_t)y * w * nB;
+        const uint8_t *o = original + (size_t)y * w * nB;
+        for (int x = 0; x < w; x++, p += nB, o += nB) {
+            if (nB > 1 && p[nC] != 255)              /* not visible (alpha != 255) */
+                continue;
+            visible++;
+            for (int b = 0; b < nC; b++) {
+                float diff = (int)p[b] - (int)o[b];
+                if (shuffle) {
+                    size_t i = ((size_t)y * w + x) * nB + b;
+                    int xn = imax(pn[i], on[i]), nx = imin(px[i], ox[i]);
+                    if (xn <= nx)
+                        diff = 0;
+                    else
+                        diff = (pn[i] > ox[i]) ? pn[i] - ox[i] : on[i] - px[i];
+                }
+                sum2 += diff * diff;
+                if (q->predict_diff && (nB == 1 || b < nB - 1))
+                    p[b] = imax(0, imin(255, 128 + (int)(diff * q->predict_diff)));
+            }
+        }
+    }
+    free(pn); free(px); free(on); free(ox);
+    *fraction_visible = visible / (float)total;
+    return sqrtf(sum2 / nC / (visible + (visible == 0)));
+}
+
+/* One frame of ComputePredictionErrors (StcEvaluate.cpp:692-758) */
+float smo_prediction_error(const uint8_t *ref, const uint8_t *frame, int w, int h, int nb,
+                           const float *fdisp, float shift, const smo_predict *q,
+                           uint8_t *resampled, float *fraction_visible)
+{
+    size_t row = (size_t)w * nb;
+    /* fill with the empty colour: the low byte for gray, the int's bytes for 4 bands (:704-717) */
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        if (nb == 1) {
+            resampled[i] = (uint8_t)q->empty_color;
+        } else {
+            int32_t c = q->empty_color;
+            memcpy(&resampled[i * 4], &c, 4);
+        }
+    }
+    if (q->predict_type == 1) {                      /* ePredictForward: the reference image moved */
+        for (int y = 0; y < h; y++)
+            forward_warp_row_u8n(ref + y * row, resampled + y * row, fdisp + (size_t)y * w, w, nb, shift,
+                                 q->lin_interp != 0, q->disp_gap);
+        return prediction_error(resampled, frame, w, h, nb, q, fraction_visible);
+    }
+    /* ePredictInverse: InverseWarp (Warp1D.cpp:196-257), cubic, with the visibility test against
+     * the forward-warped depth map */
+    float *fwd = NULL, *fwd_tmp = NULL;
+    if (q->disp_gap > 0.0f) {
+        fwd = malloc((size_t)w * h * sizeof(float));
+        fwd_tmp = malloc((size_t)w * sizeof(float));
+        for (size_t i = 0; i < (size_t)w * h; i++)
+            fwd[i] = -9999.0f;
+        for (int y = 0; y < h; y++) {
+            const float *dp = fdisp + (size_t)y * w;
+            for (int x = 0; x < w; x++)              /* ScaleAndOffset(disp, fwd_tmp, d_scale, 0) */
+                fwd_tmp[x] = (shift != 1.0f) ? dp[x] * shift + 0.0f : dp[x];
+            forward_warp_row(fwd_tmp, fwd + (size_t)y * w, dp, w, shift, q->disp_gap, 0);
+        }
+    }
+    float *src_buf = malloc(row * sizeof(float)), *dst_buf = malloc(row * sizeof(float));
+    float *dsp_buf = malloc((size_t)w * sizeof(float));
+    for (int y = 0; y < h; y++) {
+        const uint8_t *ps = frame + y * row;
+        uint8_t *pd = resampled + y * row;
+        const float *dp = fdisp + (size_t)y * w;
+        for (size_t i = 0; i < row; i++) {
+            src_buf[i] = ps[i];
+            dst_buf[i] = pd[i];
+        }
+        for (int x = 0; x < w; x++)
+            dsp_buf[x] = (shift != 1.0f) ? dp[x] * shift + 0.0f : dp[x];
+        inverse_warp_line(src_buf, dst_buf, dsp_buf, w, nb, 3, fwd ? fwd + (size_t)y * w : NULL, q->disp_gap);
+        for (size_t i = 0; i < row; i++) {           /* back to uchar: + 0.5, clipped, truncated */
+            float val = dst_buf[i] * 1.0f + 0.5f;
+            val = val > 0 ? val : 0;
+            val = val < 255 ? val : 255;
+            pd[i] = (uint8_t)val;
+        }
+    }
+    free(src_buf); free(dst_buf); free(dsp_buf); free(fwd); free(fwd_tmp);
+    return prediction_error(resampled, ref, w, h, nb, q, fraction_visible);
+}
+
+/* ------------------------------------------------------------------------- */
 /* scan-line optimisation: StcOptSO.cpp:30-154 with the horizontal smoothness */
 /* weights of ComputeSmoothnessCosts (StcOptimize.cpp:84-116, band 1)          */
 

@@ -148,6 +148,23 @@ typedef struct smo_eval_out {
 void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
                   const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out);
 
+/* Prediction (re-projection) error of one frame (ComputePredictionErrors, StcEvaluate.cpp:588-758;
+ * ForwardWarp / InverseWarp, Warp1D.cpp:25-257).  ref = the un-preprocessed reference image, frame =
+ * that frame's input image (tight rows, nb bands each), shift = (f - frame_ref) / |frame_match -
+ * frame_ref|.  Writes the re-projected image (what resampled_file receives), returns the RMS error
+ * over visible pixels and the visible fraction.  No reference output pins it: parity unpinned. */
+typedef struct smo_predict {
+    int predict_type;                   /* 1 = forward warp of ref, 2 = inverse warp of frame */
+    int lin_interp;
+    float disp_gap;
+    int predict_diff;
+    int empty_color;
+    float partial_shuffle;
+} smo_predict;
+float smo_prediction_error(const uint8_t *ref, const uint8_t *frame, int w, int h, int nb,
+                           const float *fdisp, float shift, const smo_predict *q,
+                           uint8_t *resampled, float *fraction_visible);
+
 /* OptSO (StcOptSO.cpp:30-154), the reference's O(D^2)-per-pixel scan, with the horizontal
  * smoothness weights of StcOptimize.cpp:61-116 computed from `ref` */
 void smo_opt_dp(const float *cost, int w, int h, int nd, long row_elems, const uint8_t *ref,

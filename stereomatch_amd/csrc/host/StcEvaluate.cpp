@@ -5,21 +5,22 @@
 // read-out.  O(W*H) host work; the two box filters (BoxFilter<float> 3x3 average over the
 // squared gradient, BoxFilter<int> 9x9 sum over the discontinuity marks) run through
 // smhip_box_filter on one-band images -- the same operator that aggregates the DSI.
-// Not restated: prediction errors by re-projection (eval_predict_type, :615-758), match quality
-// (:760-863) and the status statistics (:865-954; WTA leaves no status map) -- their outputs
-// keep the "not computed" value -1.
+// Prediction (re-projection) errors (:588-758, ForwardWarp / InverseWarp Warp1D.cpp:58-257) fill
+// predict_err_* and the frames' resampled images.  Not restated: match quality (:760-863) and the
+// status statistics (:865-954; WTA leaves no status map).
 #include "StereoMatcher.h"
 #include "Error.h"
 #include <cmath>
+#include <vector>
 
 #define ROUND(x) ((int)((x) >= 0 ? (x) + .5 : (x) - .5))     // Warp1D.cpp:23
 
 namespace {
 
-// draw_intensity_line (Warp1D.cpp:25-56) for one band.  T = float: no clipping, no rounding
-// offset; T = uchar: + 0.5, clipped to [0, 255], truncated.
+// draw_intensity_line (Warp1D.cpp:25-56), all bands of a pixel.  T = float: no clipping, no
+// rounding offset; T = uchar: + 0.5, clipped to [0, 255], truncated.
 template <class T>
-void DrawLine(const T *src1, const T *src2, T *dst, float x1, float x2, int w)
+void DrawLine(const T *src1, const T *src2, T *dst, float x1, float x2, int w, int nb)
 {
     if (x2 < x1)
         return;                                               // backward facing line
@@ -29,26 +30,30 @@ void DrawLine(const T *src1, const T *src2, T *dst, float x1, float x2, int w)
     float iden = 1.0 / (x2 - x1 + (x2 == x1));
     for (int i = i0; i <= i1; i++) {
         float f = (i - x1) * iden;
-        float v1 = src1[0], v2 = src2[0];
-        float v = v1 + f * (v2 - v1);
-        if (is_float) {
-            dst[i] = (T)(v + 0.0f);
-        } else {
-            float r = v + 0.5f;
-            r = r > 0 ? r : 0;
-            r = r < 255 ? r : 255;
-            dst[i] = (T)r;
+        T *dp = dst + (size_t)i * nb;
+        for (int b = 0; b < nb; b++) {
+            float v1 = src1[b], v2 = src2[b];
+            float v = v1 + f * (v2 - v1);
+            if (is_float) {
+                dp[b] = (T)(v + 0.0f);
+            } else {
+                float r = v + 0.5f;
+                r = r > 0 ? r : 0;
+                r = r < 255 ? r : 255;
+                dp[b] = (T)r;
+            }
         }
     }
 }
 
-// ForwardWarp (Warp1D.cpp:58-128) of a one-band image with line interpolation
+// ForwardWarp (Warp1D.cpp:58-128): pixels of src move by -d_scale * disp; pixels of dst nothing
+// lands on keep their value
 template <class T>
-void ForwardWarp1(const CImageOf<T> &src, CImageOf<T> &dst, const CFloatImage &disp, float d_scale,
-                  float disp_gap)
+void ForwardWarp(const CImageOf<T> &src, CImageOf<T> &dst, const CFloatImage &disp, float d_scale,
+                 bool line_interpolate, float disp_gap)
 {
     CShape sh = src.Shape();
-    int w = sh.width, h = sh.height;
+    int w = sh.width, h = sh.height, nb = sh.nBands;
     for (int y = 0; y < h; y++) {
         int xstart = d_scale > 0 ? 0 : w - 1, xend = d_scale > 0 ? w : -1, xincr = d_scale > 0 ? 1 : -1;
         const float *dp = disp.Row(y);
@@ -56,21 +61,126 @@ void ForwardWarp1(const CImageOf<T> &src, CImageOf<T> &dst, const CFloatImage &d
         T *pd = dst.Row(y);
         for (int x = xstart; x != xend; x += xincr) {
             int x2 = x + xincr;
-            bool draw_line = (x2 != xend) && (std::fabs(dp[x] - dp[x2]) < disp_gap);
+            bool draw_line = line_interpolate && (x2 != xend) && (std::fabs(dp[x] - dp[x2]) < disp_gap);
             float d = d_scale * dp[x];
             if (draw_line) {
                 float d2 = d_scale * dp[x2];
                 if (xincr > 0)
-                    DrawLine(&ps[x], &ps[x2], pd, x - d, x2 - d2, w);
-                else
-                    DrawLine(&ps[x2], &ps[x], pd, x2 - d, x - d2, w);   // as written at Warp1D.cpp:115-117
+                    DrawLine(&ps[(size_t)x * nb], &ps[(size_t)x2 * nb], pd, x - d, x2 - d2, w, nb);
+                else                                          // as written at Warp1D.cpp:115-117
+                    DrawLine(&ps[(size_t)x2 * nb], &ps[(size_t)x * nb], pd, x2 - d, x - d2, w, nb);
                 continue;
             }
             int xx = x - ROUND(d);
             if (xx >= 0 && xx < w)
-                pd[xx] = ps[x];
+                memcpy(&pd[(size_t)xx * nb], &ps[(size_t)x * nb], nb * sizeof(T));
         }
     }
+}
+
+// CubicInterpolate (Warp1D.cpp:130-142)
+inline float CubicInterpolate(float x0, float v0, float v1, float v2, float v3)
+{
+    float x1 = 1.0f - x0;
+    float s0 = v2 - v0, s1 = v1 - v3, d1 = v2 - v1;
+    float phi0 = d1 * (x0 * x0) * (2.0f * x1 + 1.0f);
+    float phi1a = s0 * x0 * (x1 * x1);
+    float phi1b = s1 * x1 * (x0 * x0);
+    return v1 + phi0 + phi1a + phi1b;
+}
+
+// InverseWarp<uchar> (Warp1D.cpp:144-257): dst(x) = src(x - d_scale * disp(x)), cubic between
+// pixels (linear next to the borders), skipped where the forward-warped depth map disagrees by
+// disp_gap or more (occluded); untouched pixels of dst keep their value
+void InverseWarp(const CByteImage &src, CByteImage &dst, const CFloatImage &disp, float d_scale,
+                 float disp_gap, int order)
+{
+    CShape sh = src.Shape();
+    int w = sh.width, h = sh.height, nb = sh.nBands, n = w * nb;
+    CFloatImage fwd;
+    if (disp_gap > 0.0f) {
+        CFloatImage scaled(disp.Shape());
+        fwd.ReAllocate(disp.Shape());
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                float v = disp.Row(y)[x];
+                scaled.Row(y)[x] = (d_scale != 1.0f) ? v * d_scale + 0.0f : v;     // Convert.cpp:31-47
+                fwd.Row(y)[x] = -9999.0f;
+            }
+        ForwardWarp(scaled, fwd, disp, d_scale, true, disp_gap);
+    }
+    std::vector<float> from(n), to(n), shift(w);
+    for (int y = 0; y < h; y++) {
+        const uchar *ps = src.Row(y);
+        uchar *pd = dst.Row(y);
+        for (int i = 0; i < n; i++) {
+            from[i] = ps[i];
+            to[i] = pd[i];
+        }
+        for (int x = 0; x < w; x++) {
+            float v = disp.Row(y)[x];
+            shift[x] = (d_scale != 1.0f) ? v * d_scale + 0.0f : v;
+        }
+        const float *vis = disp_gap > 0.0f ? fwd.Row(y) : nullptr;
+        for (int x = 0; x < w; x++) {                         // InverseWarpLine, :144-194
+            float d = shift[x];
+            float at = x - d;
+            if (at < 0.0 || at > w - 1)
+                continue;
+            int xx = int(at);
+            if (vis && disp_gap && std::fabs(d - vis[xx]) >= disp_gap)
+                continue;
+            const float *p0 = &from[(size_t)xx * nb];
+            float *out = &to[(size_t)x * nb];
+            if (order == 0 || xx == at) {
+                for (int b = 0; b < nb; b++) out[b] = p0[b];
+            } else if (order == 1 || xx - 1 < 0 || xx + 2 > w - 1) {
+                float f = at - xx;
+                for (int b = 0; b < nb; b++) out[b] = p0[b] + f * (p0[nb + b] - p0[b]);
+            } else if (order == 3) {
+                float f = at - xx;
+                for (int b = 0; b < nb; b++)
+                    out[b] = CubicInterpolate(f, p0[b - nb], p0[b], p0[nb + b], p0[2 * nb + b]);
+            } else {
+                throw CError("InverseWarp: order = %d not implemented", order);
+            }
+        }
+        for (int i = 0; i < n; i++) {                         // back to uchar: + 0.5, clipped, truncated
+            float v = to[i] * 1.0f + 0.5f;
+            v = v > 0 ? v : 0;
+            v = v < 255 ? v : 255;
+            pd[i] = (uchar)v;
+        }
+    }
+}
+
+// Min/MaxFilter<uchar> 3x3 of every band, replicate border (what MinFilter.cpp:122-202 computes for
+// xWidth = yWidth = 3), then the partially shuffled interval (PartialShuffle, StcEvaluate.cpp:588-614)
+void PartialShuffle(const CByteImage &img, CByteImage &lo, CByteImage &hi, float amt)
+{
+    CShape sh = img.Shape();
+    int w = sh.width, h = sh.height, nb = sh.nBands;
+    lo.ReAllocate(sh);
+    hi.ReAllocate(sh);
+    auto at = [&](int x, int y, int b) {
+        x = x < 0 ? 0 : (x >= w ? w - 1 : x);
+        y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+        return (int)img.Pixel(x, y, b);
+    };
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++)
+            for (int b = 0; b < nb; b++) {
+                int mn = 255, mx = 0;
+                for (int dy = -1; dy <= 1; dy++)
+                    for (int dx = -1; dx <= 1; dx++) {
+                        int v = at(x + dx, y + dy, b);
+                        mn = std::min(mn, v);
+                        mx = std::max(mx, v);
+                    }
+                int c = img.Pixel(x, y, b);
+                lo.Pixel(x, y, b) = int(c + amt * (mn - c));                  // round down
+                hi.Pixel(x, y, b) = int(c + amt * (mx - c) + 0.99f);          // round up
+            }
 }
 
 }  // namespace
@@ -99,13 +209,13 @@ void CStereoMatcher::ComputeOcclusions()
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             fwd_depth.Row(y)[x] = invalid_depth;
-    ForwardWarp1(m_true_disparity, fwd_depth, m_true_disparity, fractional_shift, eval_disp_gap);
+    ForwardWarp(m_true_disparity, fwd_depth, m_true_disparity, fractional_shift, true, eval_disp_gap);
     CByteImage white(sh);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++)
             white.Row(y)[x] = (fwd_depth.Row(y)[x] == invalid_depth) ? 0 : 255;
     m_occlusion.ReAllocate(sh);                               // pixels nothing maps to stay 0
-    ForwardWarp1(white, m_occlusion, fwd_depth, -fractional_shift, eval_disp_gap);
+    ForwardWarp(white, m_occlusion, fwd_depth, -fractional_shift, true, eval_disp_gap);
     // black borders (no statistics there), then visibility -> occlusion (:86-107)
     int b = eval_ignore_border;
     for (int y = 0; y < h; y++) {
@@ -250,6 +360,95 @@ void CStereoMatcher::ComputeDisparityErrors()
     }
 }
 
+void CStereoMatcher::ComputePredictionError(CByteImage &predicted, const CByteImage &original,
+                                            float &rms_error, float &fraction_visible)
+{
+    // StcEvaluate.cpp:615-690: squared colour differences over the visible (alpha == 255) pixels
+    CShape sh = predicted.Shape();
+    int w = sh.width, h = sh.height, nB = sh.nBands;
+    int nC = nB - (nB > 1);
+    float sum2 = 0.0;
+    int visible = 0, total = w * h;
+    CByteImage pred_min, pred_max, orig_min, orig_max;
+    bool shuffle = eval_partial_shuffle > 0.0f;
+    if (shuffle) {
+        PartialShuffle(predicted, pred_min, pred_max, eval_partial_shuffle);
+        PartialShuffle(original, orig_min, orig_max, eval_partial_shuffle);
+    }
+    for (int y = 0; y < h; y++) {
+        uchar *p = predicted.Row(y);
+        const uchar *o = original.Row(y);
+        for (int x = 0; x < w; x++, p += nB, o += nB) {
+            if (nB > 1 && p[nC] != 255)
+                continue;
+            visible++;
+            for (int b = 0; b < nC; b++) {
+                float diff = int(p[b]) - int(o[b]);
+                if (shuffle) {
+                    int pn = pred_min.Pixel(x, y, b), px = pred_max.Pixel(x, y, b);
+                    int on = orig_min.Pixel(x, y, b), ox = orig_max.Pixel(x, y, b);
+                    if (std::max(pn, on) <= std::min(px, ox))
+                        diff = 0;                             // the intervals overlap
+                    else
+                        diff = (pn > ox) ? pn - ox : on - px; // the gap between them
+                }
+                sum2 += diff * diff;
+                if (eval_predict_diff && (nB == 1 || b < nB - 1))
+                    p[b] = std::max(0, std::min(255, 128 + int(diff * eval_predict_diff)));
+            }
+        }
+    }
+    rms_error = std::sqrt(sum2 / nC / (visible + (visible == 0)));
+    fraction_visible = visible / (float)total;
+}
+
+void CStereoMatcher::ComputePredictionErrors()
+{
+    // StcEvaluate.cpp:692-758: every frame is predicted from the reference image and the computed
+    // disparities (forward warp) or pulled back onto the reference (inverse warp, cubic)
+    const int inverse_warp_order = 3;
+    for (int f = 0; f < (int)m_frame.size(); f++) {
+        CStereoFrame &frame = m_frame[f];
+        const CByteImage &original = frame.input_image;
+        CByteImage &resampled = frame.resampled_image;
+        CShape sh = original.Shape();
+        if (sh != m_reference.Shape())
+            throw CError("ComputePredictionErrors: frame %d has another shape than the reference frame", f);
+        resampled.ReAllocate(sh);
+        for (int y = 0; y < sh.height; y++) {                 // the empty colour (ARGB; alpha must be 0)
+            uchar *r = resampled.Row(y);
+            for (int x = 0; x < sh.width; x++) {
+                if (sh.nBands == 1)
+                    r[x] = (uchar)eval_empty_color;
+                else
+                    memcpy(&r[4 * x], &eval_empty_color, 4);
+            }
+        }
+        float fractional_shift = (f - frame_ref) / std::fabs((float)m_frame_diff);
+        if (eval_predict_type == 1) {
+            ForwardWarp(m_reference, resampled, m_float_disparity, fractional_shift, eval_lin_interp != 0,
+                        eval_disp_gap);
+            ComputePredictionError(resampled, original, frame.predict_err, frame.predict_visible);
+        } else {
+            InverseWarp(original, resampled, m_float_disparity, fractional_shift, eval_disp_gap,
+                        inverse_warp_order);
+            ComputePredictionError(resampled, m_reference, frame.predict_err, frame.predict_visible);
+        }
+        if (verbose >= eVerbosePredictionError)
+            fprintf(stderr, " prediction error for frame %d: RMS error = %.2f, visible = %.2f%%\n", f,
+                    frame.predict_err, frame.predict_visible * 100);
+        // view positions (0 = ref, 1 = match): near -0.5 or -1, middle 0.5, match 1, far 1.5 or 2
+        if (2 * f == 4 * frame_ref - 2 * frame_match || 2 * f == 3 * frame_ref - 1 * frame_match)
+            predict_err_near = frame.predict_err;
+        if (2 * f == 1 * frame_ref + 1 * frame_match)
+            predict_err_middle = frame.predict_err;
+        if (2 * f == 0 * frame_ref + 2 * frame_match)
+            predict_err_match = frame.predict_err;
+        if (2 * f == -1 * frame_ref + 3 * frame_match || 2 * f == -2 * frame_ref + 4 * frame_match)
+            predict_err_far = frame.predict_err;
+    }
+}
+
 void CStereoMatcher::Evaluate()
 {
     // StcEvaluate.cpp:957-984
@@ -259,8 +458,8 @@ void CStereoMatcher::Evaluate()
     ComputeTextureless();
     ComputeDisparityDiscont();
     ComputeDisparityErrors();
-    if (eval_predict_type != 0 && verbose >= eVerboseProgress)
-        fprintf(stderr, "\n  (prediction errors by re-projection are not computed: predict_err_* stay -1)");
+    if (eval_predict_type != 0)
+        ComputePredictionErrors();
     if (verbose >= eVerboseSummary)
         fprintf(stderr, "\n");
 }

@@ -222,6 +222,11 @@ void CStereoIO::WriteData()
                 fprintf(stderr, "writing image %s\n", m_fd0.depth_file);
             WriteImage(fr.depth_image, m_fd0.depth_file);
         }
+        if (m_fd0.resampled_file[0] && fr.resampled_image.Shape().height > 0) {   // StereoIO.cpp:95-112
+            if (verbose >= eVerboseFileIO)
+                fprintf(stderr, "writing image %s\n", m_fd0.resampled_file);
+            WriteImage(fr.resampled_image, m_fd0.resampled_file);
+        }
         if (stream)
             m_dio.WriteToStream(stream, true);
     }

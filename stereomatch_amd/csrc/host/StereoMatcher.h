@@ -11,6 +11,7 @@
 
 struct CStereoFrame {
     CByteImage input_image, depth_image, truth_image, resampled_image;
+    float predict_err = -1.0f, predict_visible = 0.0f;    // re-projection error of this frame (StereoMatcher.h:52-53)
 };
 
 class CStereoMatcher : public CStereoParameters {
@@ -42,6 +43,9 @@ protected:
     void ComputeTextureless();
     void ComputeDisparityDiscont();
     void ComputeDisparityErrors();
+    void ComputePredictionErrors();
+    void ComputePredictionError(CByteImage &predicted, const CByteImage &original, float &rms_error,
+                                float &fraction_visible);
     void BoxFilterOnDevice(CFloatImage &img, int window, bool average);
 
     void Check(int rc);                 // smhip status -> CError
