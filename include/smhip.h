@@ -242,6 +242,14 @@ int smhip_fused_box_dsi(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
 int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems,
                            const smhip_match_params *p, int min_window, int d_first, int d_count,
                            int64_t *d_keys);
+/* PadCosts + OptWTA (StcRawCosts.cpp:437-476, StcOptimize.cpp:26-56) on a resident slab of d_count
+ * levels (global levels d_first ...), whatever aggregated it: pads d_cost in place like smhip_pad_costs,
+ * keys out (same format as smhip_fused_box_wta_keys).  With smhip_raw_costs on the slab (disp_min +
+ * d_first * disp_num, disp_n = d_count) and any per-level aggregator (box, binomial, diffusion, min
+ * filter: all independent per level) this shards every WTA configuration by disparity slab; the one
+ * exchange is the MIN all-reduce of the keys.  disp_den == 1. */
+int smhip_pad_wta_keys(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip_match_params *p,
+                       int d_first, int d_count, int64_t *d_keys);
 /* column-major keys -> row-major disparity and best cost images (either may be NULL) */
 int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int height,
                       int32_t *d_disp, float *d_best);

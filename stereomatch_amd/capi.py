@@ -24,7 +24,7 @@ SYMBOLS = [
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
-    "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run",
+    "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run", "smhip_pad_wta_keys",
 ]
 
 
@@ -134,6 +134,7 @@ def load():
     L.smhip_convolve_14641_run.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, C.POINTER(ci)]
     L.smhip_fused_box_dsi.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp, sz]
     L.smhip_min_pad_wta_keys.argtypes = [vp, vp, sz, pp, ci, ci, ci, vp]
+    L.smhip_pad_wta_keys.argtypes = [vp, vp, sz, pp, ci, ci, vp]
     L.smhip_preprocess_blur.argtypes = [vp, vp, sz, ci, ci, ci, ci]
     L.smhip_opt_so.argtypes = [vp, vp, ci, ci, ci, sz, vp, sz, ci, cf, cf, cf, vp, vp]
     L.smhip_opt_dp.argtypes = [vp, vp, ci, ci, ci, sz, vp, sz, ci, cf, cf, cf, ci, vp, vp]
@@ -319,6 +320,10 @@ class Context:
     def min_pad_wta_keys(self, d_cost, row_elems, p, min_window, d_first, d_count, d_keys):
         self._chk(self.L.smhip_min_pad_wta_keys(self.h, _ptr(d_cost), row_elems, C.byref(p), min_window,
                                                 d_first, d_count, _ptr(d_keys)))
+
+    def pad_wta_keys(self, d_cost, row_elems, p, d_first, d_count, d_keys):
+        self._chk(self.L.smhip_pad_wta_keys(self.h, _ptr(d_cost), row_elems, C.byref(p), d_first, d_count,
+                                            _ptr(d_keys)))
 
     def opt_so(self, d_cost, w, h, nb, row_elems, d_ref, img_pitch, img_bands, smoothness, grad_thresh,
                grad_penalty, d_disp, d_best):

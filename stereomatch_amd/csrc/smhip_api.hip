@@ -1402,6 +1402,40 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     return SMHIP_OK;
 }
 
+int smhip_pad_wta_keys(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip_match_params *p,
+                       int d_first, int d_count, int64_t *d_keys)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!p || !d_keys)
+        return fail(SMHIP_EINVAL, "null argument");
+    if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
+        return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count, p->disp_n);
+    if (p->disp_den != 1)
+        return fail(SMHIP_EINVAL, "PadCosts + WTA keys: disp_step < 1 not supported, use the stage calls");
+    int w = p->width, h = p->height;
+    rc = check_dsi(d_cost, w, h, d_count, row_elems);
+    if (rc) return rc;
+    // the slab is a DSI of its own whose first level has disparity disp_min + d_first * disp_num
+    smhip_match_params ps = *p;
+    ps.disp_min = p->disp_min + d_first * p->disp_num;
+    ps.disp_n = d_count;
+    rc = smhip_pad_costs(ctx, d_cost, row_elems, &ps);
+    if (rc) return rc;
+    size_t n_pix = (size_t)w * h;
+    void *win = nullptr;
+    rc = ws_get(ctx, WS_KEYS, n_pix * 8, &win);
+    if (rc) return rc;
+    int32_t *disp = (int32_t *)win;
+    float *best = (float *)win + n_pix;
+    rc = smhip_wta(ctx, d_cost, w, h, d_count, row_elems, disp, best);
+    if (rc) return rc;
+    dim3 grid((w + 31) / 32, (h + 31) / 32);
+    smk::keys_encode_t_kernel<<<grid, 256, 0, ctx->stream>>>(disp, best, w, h, d_first, (long long *)d_keys);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
 int smhip_profile_begin(smhip_ctx *ctx, int max_calls)
 {
     int rc = check_ctx(ctx);

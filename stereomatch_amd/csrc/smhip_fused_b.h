@@ -246,4 +246,29 @@ __global__ void keys_decode_t_kernel(const long long *__restrict__ keys, int W, 
     }
 }
 
+// Row-major winners of a slab (local level + best cost) -> column-major keys with the global
+// level d_first + d: the inverse tiling of keys_decode_t_kernel.
+__global__ void keys_encode_t_kernel(const int32_t *__restrict__ disp, const float *__restrict__ best,
+                                     int W, int H, int d_first, long long *__restrict__ keys)
+{
+    __shared__ long long tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8 threads
+    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int yy = y0 + ty + 8 * i, xx = x0 + tx;
+        if (xx < W && yy < H) {
+            size_t j = (size_t)yy * W + xx;
+            tile[tx][ty + 8 * i] = make_key(ordered_bits(best[j]), d_first + disp[j]);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int xx = x0 + ty + 8 * i, yy = y0 + tx;
+        if (xx < W && yy < H)
+            keys[(size_t)xx * H + yy] = tile[ty + 8 * i][tx];
+    }
+}
+
 }  // namespace smk

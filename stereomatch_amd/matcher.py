@@ -64,6 +64,7 @@ class StereoMatcher(StereoParameters):
         self.ctx = ctx if ctx is not None else capi.Context(device)
         self.allow_fused = True
         self.used_fused = False
+        self._slab = None                  # (whole-volume params, d_first, d_count, key buffer) in ComputeSlabKeys
         self._bufs = {}
 
     # -- device buffers (re-used across calls while the size fits)
@@ -154,6 +155,55 @@ class StereoMatcher(StereoParameters):
         best = c.download(self.d_best, (h, w), np.float32)
         return disp, best, self._depth_image(self.m_float_disparity)
 
+    def ComputeSlabKeys(self, ref, mtc, d_first, d_count):
+        """One rank's share of ComputeCorrespondence under disparity-slab sharding: levels
+        [d_first, d_first + d_count) of the same parameters through PreProcess / RawCosts / Aggregate /
+        PadCosts / OptWTA, result = the device buffer of per-pixel keys (column-major int64, global
+        levels) whose MIN over the slabs is OptWTA's answer on the whole DSI.  Every aggregator but the
+        Bayesian one treats the levels independently (BoxFilter.cpp:119-125, Convolve.cpp:166-254,
+        StcDiffusion.cpp:28-137, MinFilter.cpp:122-202), so the slab is a DSI of its own whose first level
+        has disparity disp_min + d_first * step."""
+        ref = np.ascontiguousarray(ref, np.uint8)
+        mtc = np.ascontiguousarray(mtc, np.uint8)
+        if ref.ndim == 2:
+            ref, mtc = ref[:, :, None], mtc[:, :, None]
+        if ref.shape != mtc.shape:
+            raise ValueError("ComputeCorrespondence: reference and matching not the same size")
+        self._derive(ref.shape)
+        if (self.opt_fn != eWTA or self.aggr_fn == eBayesian or self.m_disp_den != 1 or self.refine_subpix
+                or self.aggr_subpixel or self.aggr_collapse):
+            raise ValueError("slab sharding needs per-level aggregation, integer steps and opt_fn WTA")
+        if d_first < 0 or d_count < 2 or d_first + d_count > self.m_disp_n:
+            raise ValueError("slab [%d, %d) must hold >= 2 of the %d levels" % (d_first, d_first + d_count, self.m_disp_n))
+        h, w, nb = ref.shape
+        self.m_pitch = w * nb
+        self.d_ref = self._buf("ref", ref.nbytes)
+        self.d_mtc = self._buf("mtc", mtc.nbytes)
+        c = self.ctx
+        c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_ref.ptr, ref.ctypes.data, ref.nbytes))
+        c._chk(c.L.smhip_memcpy_h2d(c.h, self.d_mtc.ptr, mtc.ctypes.data, mtc.nbytes))
+        self.PreProcess()
+        keys = self._buf("keys", w * h * 8)
+        whole = self.m_params
+        self.used_fused = self._fusable()
+        if self.used_fused:
+            c.fused_box_wta_keys(self.d_ref, self.d_mtc, self.m_pitch, whole, self.aggr_window_size,
+                                 d_first, d_count, keys)
+            return keys
+        self.m_params = capi.match_params(
+            w, h, nb, d_count, disp_min=self.disp_min + d_first * self.m_disp_num, disp_num=self.m_disp_num,
+            disp_den=1, frame_diff_sign=self.m_frame_diff_sign, match_fn=self.match_fn,
+            match_interp=self.match_interp, match_max=self.match_max,
+            match_interval=1 if self.match_interval else 0, match_interpolated=self.match_interpolated)
+        self._slab = (whole, d_first, d_count, keys)
+        try:
+            self.RawCosts()
+            self.Aggregate()
+        finally:
+            self._slab = None
+            self.m_params = whole
+        return keys
+
     def PreProcess(self):  # StcPreProcess.cpp:31-56, on the device copies of the two frames
         if self.preproc_blur_iter > 0:
             p = self.m_params
@@ -212,6 +262,18 @@ class StereoMatcher(StereoParameters):
                     self.d_cost = es
         else:
             raise ValueError("CStereoMatcher::Aggregate(): unknown aggregation function")
+        if self._slab is not None:                                       # :351-365 + OptWTA on a slab -> keys
+            whole, d_first, d_count, keys = self._slab
+            if self.aggr_minfilter > 1 and self._min_wta_fusable():
+                c.min_pad_wta_keys(self.d_cost, re, whole, self.aggr_minfilter, d_first, d_count, keys)
+                return
+            if self.aggr_minfilter > 1:
+                other = self._buf("cost2", nbytes)
+                c.min_filter_to(self.d_cost, other, w, h, nb, re, self.aggr_minfilter)
+                self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
+                self.d_cost = other
+            c.pad_wta_keys(self.d_cost, re, whole, d_first, d_count, keys)
+            return
         if self.aggr_minfilter > 1 and self._min_wta_fusable():          # :351-365 + OptWTA, no DSI write
             keys = self._buf("keys", w * h * 8)
             c.min_pad_wta_keys(self.d_cost, re, p, self.aggr_minfilter, 0, nb, keys)

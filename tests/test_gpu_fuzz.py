@@ -139,3 +139,50 @@ def test_random_slab_partition(gpu_ctx, oracle, seed):
     d, c = sharding.decode_keys(merged)
     assert np.array_equal(d.T, odisp), (seed, cuts)
     util.assert_bit_equal(np.ascontiguousarray(c.T), obest, "best cost %s" % cuts)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_slab_pipeline(gpu_ctx, oracle, seed):
+    """Disparity-slab sharding of the STAGED pipeline (matcher.ComputeSlabKeys): the random
+    configurations above restricted to what shards (WTA, integer steps, per-level aggregators), the
+    level range cut into random slabs, each slab through PreProcess / RawCosts / Aggregate /
+    smhip_pad_wta_keys (or the fused calls where they apply), keys merged by MIN -- what the int64
+    all-reduce does -- and decoded: equal to the oracle's single-volume disparities and costs."""
+    from stereomatch_amd import sharding
+    w, h, b, seq, kw, structured = draw(3000 + seed)
+    if seq["disp_step"] < 1.0:
+        seq["disp_step"] = 1.0
+    seq["disp_max"] = seq["disp_min"] + max(4, int((seq["disp_max"] - seq["disp_min"]) // seq["disp_step"] * seq["disp_step"]))
+    kw.update(opt_fn=1, aggr_subpixel=0, aggr_collapse=0, refine_subpix=0)
+    kw.pop("match_interpolated", None)
+    if structured:
+        ref, mtc, _ = synth.scene_pair(w, h, 16, n_bands=b, seed=77 + seed)
+    else:
+        ref, mtc = synth.noise_pair(w, h, b, seed=99 + seed)
+    p = oracle.make_params(w, h, b, **seq, **kw)
+    if kw["aggr_fn"] == 1 and kw["aggr_iter"] > 0 and kw["aggr_window_size"] > min(w, h):
+        return                                       # outside the box filter's domain (see above)
+    odisp, obest, _, _, _ = oracle.compute_correspondence_f(ref, mtc, p)
+    D = p.disp_n
+    r = np.random.RandomState(7000 + seed)
+    n_slabs = int(r.randint(1, min(5, D // 2) + 1))
+    cuts = [0, D]
+    while len(cuts) < n_slabs + 1:                   # every slab holds at least two levels
+        c = int(r.randint(2, D - 1))
+        if all(abs(c - o) >= 2 for o in cuts):
+            cuts.append(c)
+        elif D < 4 * n_slabs:
+            break
+    cuts = sorted(cuts)
+    for fused in (True, False):
+        m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+        m.allow_fused = fused
+        merged = None
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            keys = m.ComputeSlabKeys(ref, mtc, lo, hi - lo)
+            k = gpu_ctx.download(keys, (w, h), np.int64)
+            merged = k if merged is None else np.minimum(merged, k)
+        d, c = sharding.decode_keys(merged)
+        what = "seed %d %s %s cuts=%s fused=%s" % (seed, seq, kw, cuts, fused)
+        assert np.array_equal(d.T, odisp), what
+        util.assert_bit_equal(np.ascontiguousarray(c.T), obest, what)

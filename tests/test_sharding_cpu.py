@@ -140,3 +140,51 @@ def test_gloo_key_reduce_pipeline(oracle, tmp_path):
         d, b = sharding.decode_keys(keys[f].T)
         assert np.array_equal(d, want[f][0])
         util.assert_bit_equal(b, want[f][1], "frame %d best cost" % f)
+
+
+def _staged_worker(rank, world, port, img_path, out_path, seq, kw):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    imgs = np.load(img_path)
+    left, right = imgs[0], imgs[1]
+    h, w, b = left.shape
+    whole = O.make_params(w, h, b, **seq, **kw)
+    d0, n = sharding.slab_bounds(whole.disp_n, world, rank)
+    # the rank's slab as a DSI of its own: first level at disp_min + d0 * step, n levels -- raw costs,
+    # aggregation and PadCosts never look at another level (what matcher.ComputeSlabKeys relies on)
+    step = seq.get("disp_step", 1.0)
+    mine = dict(seq, disp_min=seq["disp_min"] + int(d0 * step), disp_max=seq["disp_min"] + int((d0 + n - 1) * step))
+    p = O.make_params(w, h, b, **mine, **kw)
+    assert p.disp_n == n
+    cost = O.aggregate(O.raw_costs(left, right, p), p)
+    local, best = O.wta(cost)
+    keys = torch.from_numpy(sharding.encode_keys(best, local + d0).T.copy())
+    sharding.all_reduce_min_keys(keys)
+    if rank == 0:
+        np.save(out_path, keys.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kw", [
+    (2, dict(aggr_fn=3, aggr_iter=3, aggr_minfilter=3, match_fn=2, match_max=20)),
+    (3, dict(aggr_fn=2, aggr_iter=2, match_interval=1, match_max=4)),
+    (2, dict(aggr_fn=4, aggr_iter=4, diff_beta=0.25, match_fn=1, match_max=1000)),
+])
+def test_gloo_staged_slabs_equal_whole_volume(oracle, tmp_path, world, kw):
+    """Every rank aggregates only its own levels (separate raw costs, iterated aggregation, shiftable
+    window, PadCosts on a DSI that starts at its first level); the merged keys equal WTA on the whole
+    volume -- the sharding rule of the staged pipeline, on the oracle."""
+    w, h = 64, 18
+    seq = dict(disp_min=-2, disp_max=21, disp_step=1.0, frame_ref=1, frame_match=0)
+    left, right, _ = synth.scene_pair(w, h, 12, n_bands=4, seed=5)
+    p = oracle.make_params(w, h, 4, **seq, **kw)
+    want_d, want_b = oracle.wta(oracle.aggregate(oracle.raw_costs(left, right, p), p))
+    ip, op = str(tmp_path / "imgs.npy"), str(tmp_path / "keys.npy")
+    np.save(ip, np.stack([left, right]))
+    mp.spawn(_staged_worker, args=(world, _free_port(), ip, op, seq, kw), nprocs=world, join=True)
+    d, b = sharding.decode_keys(np.load(op).T)
+    assert np.array_equal(d, want_d)
+    util.assert_bit_equal(b, want_b, "merged best cost")
