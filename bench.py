@@ -240,6 +240,24 @@ def extra_configs(np, capi, synth, ctx):
                 "frac_of_8N_per_iteration": round(8.0 * N * iters / dt / 1e9 / HBM_PEAK_GBS, 3)}
         a.free()
         b.free()
+        # one GPU's share of config 4 under slab sharding (D = 512 over 8 GPUs): the staged pipeline on
+        # levels 256..319 -- raw costs, 4 binomial iterations, PadCosts + WTA -> keys
+        n, d0 = 64, 256
+        ps = capi.match_params(W, H, 1, n, disp_min=d0, match_fn=1, match_interval=1)
+        a, b, keys = ctx.alloc(W * H * n * 4), ctx.alloc(W * H * n * 4), ctx.alloc(W * H * 8)
+
+        def slab_step():
+            ctx.raw_costs(d_ref, d_mtc, W, ps, a, W * n)
+            in_b = ctx.convolve_14641_run(a, b, W, H, n, W * n, 4)
+            ctx.pad_wta_keys(b if in_b else a, W * n, p, d0, n, keys)
+        dt = timed(slab_step, 3)
+        res["config4_slab_pipeline"] = {
+            "workload": "3840x2160, levels 256..319 of D=512 (one GPU's share of 8): raw costs + 4 binomial "
+                        "iterations + PadCosts + WTA -> keys",
+            "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(W * H * n / dt / 1e9, 1)}
+        a.free()
+        b.free()
+        keys.free()
     except Exception as e:      # noqa: BLE001 - reported, the headline line must still print
         res["config4_error"] = repr(e)
     try:

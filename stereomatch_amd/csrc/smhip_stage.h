@@ -249,38 +249,50 @@ __device__ __forceinline__ int seg_min_all(int v)
     return v;
 }
 
-template <int SEG>
+template <int SEG, int PPT>
 __global__ __launch_bounds__(256) void wta_seg_kernel(const float *__restrict__ cost, int W, int H, int D,
                                                       size_t row_elems, int32_t *__restrict__ disp,
                                                       float *__restrict__ best)
 {
+    // a block covers PPT * 256 / SEG consecutive pixels of row y; every thread issues its PPT loads
+    // (one pixel each, 256 / SEG pixels apart) before the first reduction
     typedef typename fvec<4>::type vec;
+    constexpr int PPB = 256 / SEG;
     const int y = blockIdx.y;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int x = t / SEG, sub = t % SEG;
-    const bool live = x < W && 4 * sub < D;
-    vec v = {0, 0, 0, 0};
-    if (live)
-        v = __builtin_nontemporal_load((const vec *)(cost + (size_t)y * row_elems + (size_t)x * D + 4 * sub));
-    int s = 0x7FFFFFFF, d = 0x7FFFFFFF;
-    float bv = 0;
-    if (live) {
+    const int sub = threadIdx.x % SEG;
+    const int x0 = blockIdx.x * (PPT * PPB) + threadIdx.x / SEG;
+    const float *row = cost + (size_t)y * row_elems + 4 * sub;
+    vec v[PPT];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int o = ordered_bits(v[e]);
-            if (o < s) {
-                s = o;
-                d = 4 * sub + e;
-                bv = v[e];
+    for (int k = 0; k < PPT; k++) {
+        const int x = x0 + k * PPB;
+        v[k] = vec{0, 0, 0, 0};
+        if (x < W && 4 * sub < D)
+            v[k] = __builtin_nontemporal_load((const vec *)(row + (size_t)x * D));
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int x = x0 + k * PPB;
+        int s = 0x7FFFFFFF, d = 0x7FFFFFFF;
+        float bv = 0;
+        if (x < W && 4 * sub < D) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                int o = ordered_bits(v[k][e]);
+                if (o < s) {
+                    s = o;
+                    d = 4 * sub + e;
+                    bv = v[k][e];
+                }
             }
         }
-    }
-    const int smin = seg_min_all<SEG>(s);
-    const int dmin = seg_min_all<SEG>(s == smin ? d : 0x7FFFFFFF);
-    const int bits = seg_min_all<SEG>(d == dmin ? __float_as_int(bv) : 0x7FFFFFFF);
-    if (sub == 0 && x < W) {
-        if (disp) disp[(size_t)y * W + x] = dmin;
-        if (best) best[(size_t)y * W + x] = __int_as_float(bits);
+        const int smin = seg_min_all<SEG>(s);
+        const int dmin = seg_min_all<SEG>(s == smin ? d : 0x7FFFFFFF);
+        const int bits = seg_min_all<SEG>(d == dmin ? __float_as_int(bv) : 0x7FFFFFFF);
+        if (sub == 0 && x < W) {
+            if (disp) disp[(size_t)y * W + x] = dmin;
+            if (best) best[(size_t)y * W + x] = __int_as_float(bits);
+        }
     }
 }
 
