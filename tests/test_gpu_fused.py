@@ -251,3 +251,22 @@ def test_chunked_row_staging(gpu_ctx, oracle, monkeypatch, w, h, b, D, win, sign
         assert m.used_fused
         assert np.array_equal(disp, odisp), force
         util.assert_bit_equal(best, obest, "best cost (SMHIP_CHUNK=%s)" % force)
+
+
+@pytest.mark.parametrize("d_first", [0, 1024, 1664, 1792])
+def test_bench_geometry_of_eight_ranks(gpu_ctx, oracle, d_first):
+    """The slabs `bench.py --gpus 8` hands out (1920 wide, D = 2048, 256 levels per rank) at reduced
+    height: the last ranks' disparities reach beyond the image width, where every cost is
+    match_outside.  Keys of one slab against the oracle run on that slab as a DSI of its own."""
+    from stereomatch_amd import sharding
+    w, h, D, n = 1920, 12, 2048, 256
+    left, right, _ = synth.scene_pair(w, h, 256)
+    p = capi.match_params(w, h, 1, D, match_fn=1, match_interval=1, match_max=1000)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    keys = gpu_ctx.alloc(w * h * 8)
+    gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, w, p, 9, d_first, n, keys)
+    d, c = sharding.decode_keys(gpu_ctx.download(keys, (w, h), np.int64))
+    odisp, obest, _, _ = oracle_run(oracle, left, right, disp_min=d_first, disp_max=d_first + n - 1,
+                                    aggr_window_size=9, match_fn=1, match_interval=1, match_max=1000)
+    assert np.array_equal(d.T, odisp + d_first)
+    util.assert_bit_equal(np.ascontiguousarray(c.T), obest, "best cost of slab %d" % d_first)
