@@ -235,6 +235,15 @@ def test_error_reporting(gpu_ctx):
     p = capi.match_params(8, 70000, 1, 8)
     with pytest.raises(capi.SmhipError, match="rows"):
         gpu_ctx.raw_costs(buf, buf, 8, p, buf, 64)
+    p = capi.match_params(16, 16, 1, 8)                           # PadCosts + WTA -> keys on a slab
+    with pytest.raises(capi.SmhipError, match="outside"):
+        gpu_ctx.pad_wta_keys(buf, 16 * 4, p, 6, 4, buf)           # levels [6, 10) of 8
+    with pytest.raises(capi.SmhipError, match="outside"):
+        gpu_ctx.pad_wta_keys(buf, 16 * 4, p, -1, 4, buf)
+    with pytest.raises(capi.SmhipError, match="row_elems"):
+        gpu_ctx.pad_wta_keys(buf, 16 * 4 - 1, p, 0, 4, buf)
+    with pytest.raises(capi.SmhipError, match="disp_step < 1"):
+        gpu_ctx.pad_wta_keys(buf, 16 * 4, capi.match_params(16, 16, 1, 8, disp_den=2), 0, 4, buf)
 
 
 @pytest.mark.parametrize("h,w,d,pad", SHAPES + [(140, 30, 8, 0), (70, 21, 12, 4)])
@@ -494,3 +503,27 @@ def test_bayesian_run_equals_iterations(gpu_ctx, h, w, d, pad, n_iter):
     util.assert_bit_equal(got[:, :w * d], want[:, :w * d], "energies after %d iterations" % n_iter)
     if pad and not in_b:
         assert np.all(got[:, w * d:] == np.float32(-7.0)), "row padding was overwritten"
+
+
+@pytest.mark.parametrize("w,h,D,lo,n,sign,dmin", [(40, 9, 16, 0, 16, 1, 0), (33, 7, 64, 20, 13, 1, -3),
+                                                     (50, 6, 200, 64, 136, -1, 2), (21, 5, 12, 11, 1, 1, 0),
+                                                     (300, 4, 384, 128, 256, 1, 0)])
+def test_pad_wta_keys_on_a_slab(gpu_ctx, oracle, w, h, D, lo, n, sign, dmin):
+    """smhip_pad_wta_keys: PadCosts + OptWTA restricted to levels [lo, lo + n) of a padded volume, keys
+    with global levels; the slab buffer ends up padded like the oracle's."""
+    from stereomatch_amd import sharding
+    full = util.rand_dsi(h, w, D, 50, "float")
+    seq = dict(disp_min=dmin, disp_max=dmin + D - 1)
+    if sign < 0:
+        seq.update(frame_ref=1, frame_match=0)
+    po = oracle.make_params(w, h, 1, **seq)
+    padded = oracle.pad_costs(full, po)[:, :, lo:lo + n]
+    wd, wb = oracle.wta(np.ascontiguousarray(padded))
+    slab = np.ascontiguousarray(full[:, :, lo:lo + n])
+    d_slab, keys = up(gpu_ctx, slab), gpu_ctx.alloc(w * h * 8)
+    p = capi.match_params(w, h, 1, D, disp_min=dmin, frame_diff_sign=sign)
+    gpu_ctx.pad_wta_keys(d_slab, w * n, p, lo, n, keys)
+    d, c = sharding.decode_keys(gpu_ctx.download(keys, (w, h), np.int64))
+    assert np.array_equal(d.T, wd + lo)
+    util.assert_bit_equal(np.ascontiguousarray(c.T), wb, "best cost")
+    util.assert_bit_equal(gpu_ctx.download(d_slab, (h, w, n), np.float32), padded, "padded slab")
