@@ -84,7 +84,7 @@ def test_random_configuration(gpu_ctx, oracle, seed):
         assert np.array_equal(depth, odepth), what
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMHIP_FUZZ_BAYES_N", "16"))))
 def test_random_bayesian_configuration(gpu_ctx, oracle, seed):
     """aggr_fn 5 over random shapes / priors, in its stated tolerance (tests/test_gpu_ops.py):
     energies within 1e-4 * max(1, |E|) after up to 8 iterations, winners equal on >= 99 %."""
@@ -107,7 +107,7 @@ def test_random_bayesian_configuration(gpu_ctx, oracle, seed):
     assert np.mean(disp == oracle.wta(want)[0]) >= 0.99
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMHIP_FUZZ_SLAB_N", "40"))))
 def test_random_slab_partition(gpu_ctx, oracle, seed):
     """The multi-GPU decomposition on random shapes: the disparity range cut into random slabs,
     smhip_fused_box_wta_keys per slab, keys merged by MIN (what the all-reduce does), decoded --
@@ -141,7 +141,7 @@ def test_random_slab_partition(gpu_ctx, oracle, seed):
     util.assert_bit_equal(np.ascontiguousarray(c.T), obest, "best cost %s" % cuts)
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SMHIP_FUZZ_PIPE_N", "120"))))
 def test_random_slab_pipeline(gpu_ctx, oracle, seed):
     """Disparity-slab sharding of the STAGED pipeline (matcher.ComputeSlabKeys): the random
     configurations above restricted to what shards (WTA, integer steps, per-level aggregators), the
