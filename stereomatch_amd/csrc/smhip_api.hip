@@ -672,6 +672,24 @@ static int multi_depth(int remaining, int passes_left)
 {
     return (remaining + passes_left - 1) / passes_left;
 }
+// Most iterations one pass may hold.  Temporal blocking trades VALU work (halo recomputation, and
+// half-empty 32-level tiles when nb <= 16) for passes over the DSI, and a pass is cheap while the
+// volume sits in the 256 MiB Infinity Cache.  Measured at 1920x1080 (scripts/run_depth.py): binomial
+// x4 with 16 levels 0.37 ms at depth 4, 0.25 ms one by one; 32..64 levels depth 2 beats depth 4 by
+// 3..11 %, 3840x2160x64 (2.1 GB) is back at depth 4 (1.68 against 1.87 ms); diffusion x10 with 16
+// levels 0.39 -> 0.32 ms at depth 2, but 384x288x16 0.084 (depth 4) against 0.088 ms; from 32 levels
+// on, and for the config-4 volume (17 GB), depth 4 wins.  SMHIP_MAXK forces a depth (tests).
+static int multi_maxk(bool binomial, int nb, size_t volume_bytes)
+{
+    if (const char *e = getenv("SMHIP_MAXK")) {
+        int k = atoi(e);
+        if (k >= 1 && k <= 4)
+            return k;
+    }
+    if (binomial)
+        return nb <= 16 ? 1 : (volume_bytes < ((size_t)1 << 30) ? 2 : 4);
+    return (nb <= 16 && volume_bytes > ((size_t)32 << 20)) ? 2 : 4;   // tsukuba-size volumes: launches count, depth 4
+}
 
 int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_cost0, int w, int h,
                         int nb, size_t row_elems, float lambda, float beta, int n_iter, int *result_in_b)
@@ -702,7 +720,8 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
     }
     float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
     float lb = lambda * beta;            // :132
-    int passes = (n_iter + 3) / 4;
+    const int maxk = multi_maxk(false, nb, row_elems * (size_t)h * sizeof(float));
+    int passes = (n_iter + maxk - 1) / maxk;
     for (int left = n_iter; left > 0; passes--) {
         int K = multi_depth(left, passes);
         dim3 grid((w + (smk::MULTI_TXT - 2 * K) - 1) / (smk::MULTI_TXT - 2 * K), gy, gz);
@@ -752,7 +771,8 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         }
         return SMHIP_OK;
     }
-    int passes = (n_iter + 3) / 4;
+    const int maxk = multi_maxk(true, nb, row_elems * (size_t)h * sizeof(float));
+    int passes = (n_iter + maxk - 1) / maxk;
     for (int left = n_iter; left > 0; passes--) {
         int K = multi_depth(left, passes);
         if (K == 1) {                               // the one-iteration tile kernel has the smaller halo

@@ -315,10 +315,14 @@ def test_subpixel_fit_collapse_refine(gpu_ctx, oracle, h, w, d):
 @pytest.mark.parametrize("h,w,d,pad", [(9, 21, 8, 0), (150, 70, 12, 0), (70, 150, 40, 4), (3, 5, 4, 0),
                                        (40, 130, 7, 1)])
 @pytest.mark.parametrize("n_iter", [1, 2, 3, 4, 5, 7, 10])
-def test_multi_iteration_passes(gpu_ctx, oracle, h, w, d, pad, n_iter):
+@pytest.mark.parametrize("maxk", ["", "4", "3"])
+def test_multi_iteration_passes(gpu_ctx, oracle, monkeypatch, h, w, d, pad, n_iter, maxk):
     """smhip_diffusion_run / smhip_convolve_14641_run: up to four iterations per pass (temporal
     blocking across tiles of 64 pixels and row segments) == n_iter single iterations of the
-    oracle, bit for bit; unaligned shapes take the one-iteration-per-pass route."""
+    oracle, bit for bit; unaligned shapes take the one-iteration-per-pass route.  The depth per pass
+    follows the shape (small volumes: 1 or 2); SMHIP_MAXK forces the deeper kernels onto these shapes."""
+    if maxk:
+        monkeypatch.setenv("SMHIP_MAXK", maxk)
     c = util.rand_dsi(h, w, d, 80 + n_iter, "float")
     c0 = util.rand_dsi(h, w, d, 81, "float")
     re = w * d + pad
