@@ -137,7 +137,8 @@ int outside_of(const smhip_match_params *p)
 
 // Fills RawArgs for levels [d_first, d_first+d_count); runs the BT pre-pass when needed.
 int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t pitch,
-                const smhip_match_params *p, int d_first, int d_count, smk::RawArgs *a)
+                const smhip_match_params *p, int d_first, int d_count, smk::RawArgs *a,
+                bool bt_in_kernel = false)
 {
     int W = p->width, H = p->height, nb = p->n_bands;
     a->pitch = pitch;
@@ -149,7 +150,7 @@ int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size
     a->outside = outside_of(p);
     a->rmn = d_ref; a->rmx = nullptr;
     a->mmn = d_mtc; a->mmx = nullptr;
-    if (p->match_interval) {
+    if (p->match_interval && !bt_in_kernel) {
         size_t img = pitch * H;
         void *bt = nullptr;
         int rc = ws_get(ctx, WS_BT, img * 4, &bt);
@@ -414,6 +415,7 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
         fa.mn = a.mmn; fa.mx = a.mmx ? a.mmx : a.mmn;
         fa.pitch = img_pitch; fa.W = W; fa.H = H; fa.D = p->disp_n;
         fa.disp0 = a.disp0; fa.dstep = a.dstep; fa.cutoff = a.cutoff; fa.outside = a.outside;
+        fa.bt_inline = 0;
         int nseg = (4096 + H - 1) / H;                 // >= 4096 workgroups when the row allows it
         int xseg = (W + nseg - 1) / nseg;
         if (xseg < 32) xseg = W < 32 ? W : 32;
@@ -1219,8 +1221,17 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     size_t trow = (size_t)W * Dp;                       // floats per image row of T
     size_t t_elems = (bands << tyshift) * trow;
 
+    // pass A stages whole rows in LDS; rows above 40 KB (4 bands: wider than 2560 pixels) are staged
+    // chunk by chunk (smhip_fused_chunk.h); SMHIP_CHUNK=1/0 forces the choice in tests
+    bool chunked = (size_t)W * (p->n_bands == 1 ? 4 : 16) > 40 * 1024;
+    if (const char *e = getenv("SMHIP_CHUNK")) chunked = atoi(e) != 0;
+    // one band, whole-row kernel: the matching row's Birchfield-Tomasi interval is formed while the row
+    // is staged, so the pre-pass over the image (bt_minmax_kernel) and its workspace are not needed
+    const bool bt_inline = tuned_a && !chunked && p->n_bands == 1 && p->match_interval &&
+                           !p->match_interpolated && !getenv("SMHIP_BT_PREPASS");
+
     smk::RawArgs a;
-    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
+    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
     if (rc) return rc;
     void *T = nullptr;
     rc = ws_get(ctx, WS_TMP, t_elems * sizeof(float), &T);
@@ -1244,14 +1255,11 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         fa.mn = a.mmn; fa.mx = a.mmx ? a.mmx : a.mmn;
         fa.pitch = img_pitch; fa.W = W; fa.H = H; fa.D = d_count;
         fa.disp0 = a.disp0; fa.dstep = a.dstep; fa.cutoff = a.cutoff; fa.outside = a.outside;
+        fa.bt_inline = bt_inline;
         int tpa = Dp < 256 ? Dp : 256;
         dim3 ga(H, Dp / tpa);
         const int nbands = p->n_bands;
         size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
-        // rows above 40 KB (4 bands: wider than 2560 pixels) are staged chunk by chunk
-        // (smhip_fused_chunk.h); SMHIP_CHUNK=1/0 forces the choice in tests
-        bool chunked = lds > 40 * 1024;
-        if (const char *e = getenv("SMHIP_CHUNK")) chunked = atoi(e) != 0;
         const int adstep = a.dstep < 0 ? -a.dstep : a.dstep;
         const int static_win = (window >= 3 && window <= 17 && (window & 1)) ? window : 0;
         int chunk_steps = static_win ? (480 / static_win) * static_win : 480;

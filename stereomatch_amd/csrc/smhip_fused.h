@@ -33,6 +33,8 @@ struct FusedA {
     int W, H, D;                // D = levels in the slab
     int disp0, dstep;           // disp(k) = disp0 + k*dstep
     int cutoff, outside;
+    int bt_inline;              // 1: mn is the matching image itself, its Birchfield-Tomasi interval is
+                                // formed while the row is staged (one band, whole-row kernel)
 };
 
 // Staged image rows.  NB = 1: one uint16 per pixel, (lower | upper << 8).  NB = 4: one uint32
@@ -45,7 +47,15 @@ template <> struct RowLds<1> {
     __device__ void stage(const FusedA &a, size_t ro, int i) const
     {
         r[i] = (uint16_t)(a.rn[ro + i] | (a.rx[ro + i] << 8));
-        m[i] = (uint16_t)(a.mn[ro + i] | (a.mx[ro + i] << 8));
+        if (a.bt_inline) {      // BirchfieldTomasiMinMax (StcRawCosts.cpp:107-128), as bt_minmax_kernel
+            const uint8_t *row = a.mn + ro;
+            const int cur = row[i], prv = row[i > 0 ? i - 1 : i], nxt = row[i < a.W - 1 ? i + 1 : i];
+            const int hl = (i > 0) ? (prv + cur + 1) / 2 : cur;
+            const int hr = (cur + nxt + 1) / 2;
+            m[i] = (uint16_t)(min(hl, min(cur, hr)) | (max(hl, max(cur, hr)) << 8));
+        } else {
+            m[i] = (uint16_t)(a.mn[ro + i] | (a.mx[ro + i] << 8));
+        }
     }
     // chunked staging (smhip_fused_chunk.h): nref reference and nmatch matching pixels,
     // slot = pixel - first pixel of the chunk
