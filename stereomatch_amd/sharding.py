@@ -56,11 +56,11 @@ class KeyReducePipeline:
     `produce(buf, frame)` enqueues the slab computation that fills key buffer `buf`;
     `consume(buf, frame)` enqueues whatever reads the merged keys (e.g. smhip_keys_decode).
     Two key buffers alternate.  The all-reduce is issued asynchronously right after
-    `produce`; the previous frame's reduce is waited for (a stream wait under RCCL, no host
-    block) and consumed only after the current frame's compute has been enqueued, so xGMI
-    traffic runs under the next frame's kernels.  Stream order on the compute stream --
-    produce(i), wait(i-1), consume(i-1), produce(i+1), ... -- also guarantees a buffer is not
-    rewritten before its consumer ran.  Call flush() after the last frame.
+    `produce` and after the previous frame's reduce has been waited for (a stream wait under
+    RCCL, no host block) and consumed, so xGMI traffic runs under the next frame's kernels and
+    one collective is in flight at a time.  Stream order on the compute stream -- produce(i),
+    wait(i-1), consume(i-1), [reduce(i) issued], produce(i+1), ... -- also guarantees a buffer
+    is not rewritten before its consumer ran.  Call flush() after the last frame.
     """
 
     def __init__(self, key_buffers, produce, consume, group=None, force_collective=False):
@@ -89,9 +89,12 @@ class KeyReducePipeline:
         buf = self.bufs[self.n & 1]
         self.n += 1
         self.produce(buf, frame)
-        work = self._reduce_async(buf)
+        # the previous frame's reduce ran under the kernels just enqueued; it is waited for and
+        # consumed before this frame's reduce is issued, so one collective is in flight at a time
+        # (two overlapping 16 MB gloo all-reduces were seen to stall each other in rehearsals; RCCL
+        # serialises collectives of one communicator on its stream anyway)
         self._drain()
-        self.pending = (work, buf, frame)
+        self.pending = (self._reduce_async(buf), buf, frame)
 
     def flush(self):
         self._drain()
