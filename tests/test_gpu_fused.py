@@ -274,15 +274,15 @@ def test_bench_geometry_of_eight_ranks(gpu_ctx, oracle, d_first):
 
 @pytest.mark.parametrize("w,h,D,win", [(96, 40, 16, 9), (1, 9, 4, 1), (2, 11, 8, 1), (130, 20, 64, 5), (300, 12, 256, 9)])
 def test_bt_interval_in_kernel_and_as_prepass(gpu_ctx, oracle, monkeypatch, w, h, D, win):
-    """One-band frames: with SMHIP_BT_INLINE=1 pass A forms the matching row's Birchfield-Tomasi interval
-    while staging the row (first and last pixel replicate, StcRawCosts.cpp:107-128) instead of reading the
-    pre-pass kernel's min / max images (the default).  Both equal the oracle."""
+    """One-band frames: pass A forms the matching row's Birchfield-Tomasi interval while staging the row
+    (first and last pixel replicate, StcRawCosts.cpp:107-128); SMHIP_BT_PREPASS=1 keeps the separate
+    pre-pass kernel that every other shape uses.  Both equal the oracle."""
     left, right = synth.noise_pair(w, h, 1, seed=w + D)
     kw = dict(disp_max=D - 1, aggr_window_size=win, match_fn=1, match_interval=1, match_max=1000)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    for prepass in (True, False):
-        if not prepass:
-            monkeypatch.setenv("SMHIP_BT_INLINE", "1")
+    for prepass in (False, True):
+        if prepass:
+            monkeypatch.setenv("SMHIP_BT_PREPASS", "1")
         m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
         disp, best, _ = m.ComputeCorrespondence(left, right)
         assert m.used_fused
