@@ -26,13 +26,18 @@ int main()
     double B = (double)W * H * Dp * 4;
     int xpx = (W + 7) / 8;
     float scale = (float)(1.0 / 9);
-#define RUN(ABL, WPB, NAME) timeit(NAME, B, [&] { dim3 g(8 * ((xpx + WPB - 1) / WPB), 1); \
-    smk::fused_boxv_wta_vpl_kernel<9, 4, ABL><<<g, 64 * WPB>>>(T, tyshift, W, H, Dp, D, 9, scale, 0, -1, 1000.f, 0, xpx, keys, (size_t)W * H); })
-    RUN(0, 4, "full, 4 waves/block");
-    RUN(0, 1, "full, 1 wave/block");
-    RUN(0, 2, "full, 2 waves/block");
-    RUN(1, 4, "no wave reduce");
-    RUN(2, 4, "no key stores");
-    RUN(3, 4, "no reduce, no key stores");
+#define RUNK(ABL, WPB, KB, NAME) timeit(NAME, B, [&] { dim3 g(8 * ((xpx + WPB - 1) / WPB), 1); \
+    smk::fused_boxv_wta_vpl_kernel<9, 4, ABL><<<g, 64 * WPB, (size_t)WPB * KB * 8>>>(T, tyshift, W, H, Dp, D, 9, scale, 0, -1, 1000.f, 0, xpx, keys, (size_t)W * H, nullptr, 0, KB); })
+#define RUN(ABL, WPB, NAME) RUNK(ABL, WPB, 0, NAME)
+    for (int rep = 0; rep < 3; rep++) {
+        RUNK(0, 4, 0, "full, unbuffered");
+        RUNK(0, 4, 63 * 18, "full, keys buffered 1134 rows");
+        RUNK(0, 4, 63 * 8, "full, keys buffered 504 rows");
+        RUNK(0, 4, 63 * 2, "full, keys buffered 126 rows");
+        RUNK(1, 4, 0, "no wave reduce, unbuffered");
+        RUNK(1, 4, 63 * 18, "no wave reduce, 1134 rows");
+        RUNK(2, 4, 0, "no key stores");
+        RUNK(3, 4, 0, "no reduce, no key stores");
+    }
     return 0;
 }

@@ -10,8 +10,11 @@
 // No LDS, no barrier: a 256-level pixel is finished inside one wave.
 //
 // Keys are written COLUMN-MAJOR (key of pixel (x,y) at x*H + y): lane (y mod G) keeps the key
-// of row y and the wave stores G consecutive keys with one instruction (G = 63 or 64 rows),
-// instead of one scattered 8-byte store per row (measured: 0.36 ms -> 0.30 ms for pass B).
+// of row y and the wave puts G consecutive keys (G = 63 or 64 rows) into a wave-private LDS
+// buffer of kb_rows rows, which goes to memory in one run when it is full or the column ends.
+// Every store into the read stream costs an HBM bus turn-around: one scattered 8-byte store per row
+// made pass B 0.36 ms, one 504-byte store per 63 rows 0.33 ms, one 9-KB run per column 0.31 ms
+// (scripts/bench_b.hip: without any key store 0.31 ms).
 #pragma once
 
 #include "smhip_fused.h"
@@ -47,8 +50,9 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
     long long *__restrict__ keys, size_t keys_chunk_stride, float *__restrict__ S = nullptr,
-    size_t s_row_elems = 0)
+    size_t s_row_elems = 0, int kb_rows = 0)          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8
 {
+    extern __shared__ __attribute__((aligned(16))) long long kbuf_all[];
     constexpr int BLK = WIN ? WIN : 8;
     constexpr int GRP = (64 / BLK) * BLK;              // rows per key store (63 for WIN 9)
     constexpr int CH = 64 * VPL;
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const int w = WIN ? WIN : win;
     const int pr = w / 2, pl = pr - w;
     long long *kout = keys + (size_t)chunk * keys_chunk_stride + (size_t)x * H;
+    long long *kbuf = kbuf_all + (size_t)wib * kb_rows;
+    int kb_first = 0;                                  // first row held in the LDS key buffer
 
     bool padded[VPL], live[VPL];
 #pragma unroll
@@ -160,8 +166,19 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                     kout[0] = make_key(key_hi, key_lo);
                 return;
             }
-            if (lane < GRP && g0 + lane < H)
-                kout[g0 + lane] = make_key(key_hi, key_lo);
+            if (kb_rows == 0) {                         // unbuffered (no dynamic LDS given)
+                if (lane < GRP && g0 + lane < H)
+                    kout[g0 + lane] = make_key(key_hi, key_lo);
+                return;
+            }
+            if (lane < GRP)
+                kbuf[g0 - kb_first + lane] = make_key(key_hi, key_lo);
+            if (g0 + GRP - kb_first == kb_rows || last) {
+                const int n = min(kb_rows, H - kb_first);
+                for (int i = lane; i < n; i += 64)
+                    kout[kb_first + i] = kbuf[i];
+                kb_first += kb_rows;
+            }
         }
     };
 

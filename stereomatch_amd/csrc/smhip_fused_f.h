@@ -1,0 +1,338 @@
+// smhip_fused_f.h -- pass A of the fused path for one-band frames, "float lanes" form.
+//
+// What the measurements of scripts/bench_a.hip and scripts/valu_rate.hip say about pass A on gfx950:
+//   * the slab stores alone take 0.34 ms at config 3 (store-only kernel, 512-B wave stores), the
+//     arithmetic of the integer kernel (smhip_fused.h) alone 0.23 ms, and the two overlap badly
+//     (0.41 ms together): every nanosecond of issue time per step shows up as ~0.3 ns of kernel time;
+//   * only v_add/sub/mul_f32 (modifiers included), v_sub_u32, v_and/or/mov issue at the full rate
+//     (1.0 ns per wave-instruction and SIMD); min/max/max3/med3, every cvt, SDWA, packed and bit-field
+//     instruction takes 1.75 ns; a wave alone on its SIMD issues one instruction per 2 ns whatever it is.
+// So this kernel spends as few instructions per level and step as the arithmetic allows:
+//   * the staged row lives in LDS as FLOATS (converted once per pixel, not once per level and step) and
+//     MatchLine (StcRawCosts.cpp:152-190) is evaluated in float: every value is an integer below 2^24,
+//     so the float results equal the reference's integers and scale * (float)(c_new - c_old) is the
+//     same product.  With the reference interval a point (no match_interpolated) the distance to the
+//     matching interval is |r - med3(lo, hi, r)|: per level and step med3, sub, sub|.|, mul, add;
+//   * two levels per lane (512-B wave stores); level i of a lane at step s uses matching pixel
+//     s + (LPL-1-i) (dstep -1) or s + i (dstep +1) of the WIN + LPL - 1 pixels the lane reads per block,
+//     prefetched one block ahead; two blocks per loop trip, so the ring never moves between registers;
+//   * buffer stores: wave-uniform descriptor and step offset, constant lane offset -- no address
+//     arithmetic per store; lanes that must not store get an out-of-range offset instead of a branch;
+//   * the row is staged in chunks (LDS and prologue independent of the width), and the bytes of the
+//     next chunk are fetched into registers while the current one is being worked on.
+// Compile with -fno-slp-vectorize (SMHIP build flags): packed f32 instructions cost two plain ones, need
+// register shuffles and cannot take the |.| modifiers.
+//
+// NOTE (gfx950, ROCm 7.2): a buffer_store_dwordx4 with an SGPR soffset whose data registers are rewritten
+// by the next VALU instruction stored the NEW value of its first data register in lanes 12-15 of every
+// 16 (seen on waves sharing a SIMD, early in the launch while the store queue is empty); the compiler
+// inserts no wait state for this form.  dwordx2 / dword stores are not affected -- LPL stays <= 2 here.
+#pragma once
+
+#include "smhip_fused_b.h"
+
+namespace smk {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// blockDim.x = 64 * NW; grid (H, Dp / (64 * LPL * NW)).  One band, |dstep| == 1 (DS), reference
+// interval a point (a.rn == a.rx).  CUT = false: cutoff >= the largest possible cost (no truncation).
+// cb = blocks (of WIN steps) per staged chunk; nref = cb * WIN + WIN, nmatch = nref + 64 * LPL * NW, both
+// <= FUSED_F_NI * 64 * NW.  Dynamic LDS: nmatch * 8 + nref * 4 bytes.  W * (Dp << tyshift) * 4 < 2^31.
+// glev = levels per lane of the pass B that follows (1, 2 or 4): the granule of the store predicate.
+constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
+
+template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0>   // ABL: ablations of scripts/bench_a.hip
+__global__ __launch_bounds__(64 * NW) void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
+                                                                   int Dp, float scale, int keep_all, int cb,
+                                                                   int nref, int nmatch, int glev)
+{
+    static_assert(WIN >= 3 && (WIN & 1), "static odd window");
+    static_assert(DS == 1 || DS == -1, "unit disparity step");
+    static_assert(LPL == 1 || LPL == 2, "levels per lane (see the note on dwordx4 buffer stores)");
+    constexpr int NT = 64 * NW;                        // threads per workgroup
+    constexpr int CW = 64 * LPL * NW;                  // levels per workgroup
+    constexpr int NPX = WIN + LPL - 1;                 // matching pixels a lane reads per block
+    constexpr int NI = FUSED_F_NI;
+    constexpr int pr = WIN / 2, pl = pr - WIN;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];
+    f32x2 *ml = (f32x2 *)lds_f;                        // matching interval (lo, hi) of positions M0 ..
+    float *rl = (float *)(ml + nmatch);                // reference value of positions R0 ..
+    const int W = a.W, D = a.D;
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int y = blockIdx.x;
+    const int kc = blockIdx.y * CW;                    // first level of this workgroup
+    const int kq = (wib * 64 + lane) * LPL;            // first level of this lane inside the chunk
+    // lanes beyond D shadow the last live lane, so disp[i] = disp[0] + i * DS in every lane
+    const int Dl = (D + LPL - 1) / LPL * LPL;
+    const int kbase = min(kc + kq, Dl - LPL);
+    int disp[LPL];
+#pragma unroll
+    for (int i = 0; i < LPL; i++)
+        disp[i] = a.disp0 + (kbase + i) * DS;
+    const int dA = a.disp0 + kc * DS, dB = a.disp0 + (min(kc + CW, Dl) - 1) * DS;
+    const int dlo = min(dA, dB), dhi = max(dA, dB);
+    // Positions q with 0 <= q + disp < W for every level of the workgroup: no bounds tests there.
+    const int qa = max(0, -dlo), qb = min(W, W - dhi);
+    const float cutf = (float)a.cutoff, outf = (float)a.outside;
+    const uint8_t *mrow = a.mn + (size_t)y * a.pitch, *xrow = a.mx + (size_t)y * a.pitch;
+    const uint8_t *rrow = a.rn + (size_t)y * a.pitch;
+    const int nblocks = (W - 1 + WIN - 1) / WIN;       // block b = steps x = 1 + WIN*b .. WIN + WIN*b
+    // blocks [b_int0, b_int1) are interior; blocks below b_edge never clamp the reference position
+    const int b_int0 = qa <= 1 ? 0 : (qa - 1 + WIN - 1) / WIN;
+    const int b_int1 = (qb - WIN - pr - 1 >= 0) ? (qb - WIN - pr - 1) / WIN + 1 : 0;
+    const int b_edge = (W - WIN - pr - 1 >= 0) ? (W - WIN - pr - 1) / WIN + 1 : 0;
+
+    // ---- chunk geometry and staging ----
+    int R0 = 0, M0 = 0;                                // first staged positions of the current chunk
+    struct Geo { int R0, R1, M0, M1; };
+    auto geometry = [&](int c0) -> Geo {
+        const int c1 = min(c0 + cb, nblocks);
+        const int xa = c0 == 0 ? 0 : 1 + WIN * c0, xe = min(W - 1, WIN * c1);
+        Geo g;
+        g.R0 = xa;
+        g.R1 = min(xe + pr, W - 1);
+        g.M0 = clampi(g.R0 + dlo, W);
+        g.M1 = clampi(g.R1 + dhi, W);
+        return g;
+    };
+    // raw bytes of a chunk, fetched one chunk ahead: matching pixel and its neighbours (or the two
+    // interval images), reference pixel
+    uint8_t f_cur[NI], f_prv[NI], f_nxt[NI], f_ref[NI];
+    auto fetch = [&](const Geo &g) {
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int i = threadIdx.x + j * NT;
+            if (ABL & 2) {                             // ablation: no global loads
+                f_cur[j] = (uint8_t)(i * 7 + y); f_prv[j] = (uint8_t)(i * 5); f_nxt[j] = (uint8_t)(i * 3 + y); f_ref[j] = (uint8_t)(i * 11 + y);
+                continue;
+            }
+            if (i <= g.M1 - g.M0) {
+                const int p = g.M0 + i;
+                if (a.bt_inline) {
+                    f_cur[j] = mrow[p];
+                    f_prv[j] = mrow[p > 0 ? p - 1 : p];
+                    f_nxt[j] = mrow[p < W - 1 ? p + 1 : p];
+                } else {
+                    f_cur[j] = mrow[p];
+                    f_nxt[j] = xrow[p];
+                }
+            }
+            if (i <= g.R1 - g.R0)
+                f_ref[j] = rrow[g.R0 + i];
+        }
+    };
+    auto commit = [&](const Geo &g) {
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            const int i = threadIdx.x + j * NT;
+            if (i <= g.M1 - g.M0) {
+                const int p = g.M0 + i;
+                int lo, hi;
+                if (a.bt_inline) {                     // BirchfieldTomasiMinMax (StcRawCosts.cpp:107-128)
+                    const int cur = f_cur[j], prv = f_prv[j], nxt = f_nxt[j];
+                    const int hl = (p > 0) ? (prv + cur + 1) / 2 : cur;
+                    const int hr = (cur + nxt + 1) / 2;
+                    lo = min(hl, min(cur, hr));
+                    hi = max(hl, max(cur, hr));
+                } else {
+                    lo = f_cur[j];
+                    hi = f_nxt[j];
+                }
+                f32x2 v = {(float)lo, (float)hi};
+                ml[i] = v;
+            }
+            if (i <= g.R1 - g.R0)
+                rl[i] = (float)f_ref[j];
+        }
+    };
+
+    // ---- arithmetic ----
+    // The ring keeps, per level and window slot, a value whose magnitude is the raw cost: without
+    // squaring and truncation the signed difference itself (|.| is a free source modifier), so the
+    // new cost is born in the register that stays in the ring.
+    constexpr bool RAW = !SD && !CUT;
+    auto mag = [](float v) -> float { return RAW ? __builtin_fabsf(v) : v; };
+    // distance between reference value r and the matching interval m (StcRawCosts.cpp:168-185)
+    auto dist = [&](float r, f32x2 m) -> float {
+        float q = r - __builtin_amdgcn_fmed3f(m.x, m.y, r);
+        if (RAW) return q;
+        float e = SD ? q * q : __builtin_fabsf(q);
+        if (CUT) e = __builtin_fminf(e, cutf);
+        return e;
+    };
+    auto cost = [&](int xr, int i) -> float {          // MatchLine for reference pixel xr, level i of the lane
+        int xm = xr + disp[i];
+        bool out = (unsigned)xm >= (unsigned)W;
+        int xc = (int)min((unsigned)max(xm, 0), (unsigned)(W - 1));
+        float e = dist(rl[xr - R0], ml[xc - M0]);
+        return out ? outf : e;
+    };
+    // Slab addresses: buffer stores with a wave-uniform descriptor (this row at x = 0, first level of the
+    // workgroup), a wave-uniform byte offset per step and a 32-bit lane offset.  Lanes beyond D write what
+    // the lane they shadow writes, to the same place; an offset of `oob` (= the descriptor's size) makes
+    // the hardware drop the store.
+    const unsigned xsb = ((unsigned)Dp << tyshift) * (unsigned)sizeof(float);   // bytes between consecutive x
+    const int oob = (int)((unsigned)W * xsb);
+    const __amdgpu_buffer_rsrc_t trs =
+        __builtin_amdgcn_make_buffer_rsrc(T + slab_row_offset(y, W, Dp, tyshift) + kc, 0, oob, 0x00020000);
+    const int lane_off = (kbase - kc) * 4;
+    unsigned tb = 0;                                   // byte offset of the current block's first step
+    auto put = [&](int voff, unsigned off, const float (&acc)[LPL]) {
+        if constexpr (LPL == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[0]), trs, voff, off, 0);
+        } else {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 v = {__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1])};
+            __builtin_amdgcn_raw_buffer_store_b64(v, trs, voff, off, 0);
+        }
+    };
+    // does one level of the lane's group of glev levels (one lane of pass B, glev a multiple of LPL)
+    // survive PadCosts at pixel x: pass B loads such a group whole and wants numbers in all of it
+    const int kg = kbase / glev * glev;
+    const int dg0 = a.disp0 + kg * DS, dg1 = a.disp0 + (kg + glev - 1) * DS;
+    auto lane_live = [&](int x) -> bool {
+        return (unsigned)(x + dg0) < (unsigned)W || (unsigned)(x + dg1) < (unsigned)W;
+    };
+
+    float acc[LPL], ring[LPL][WIN];
+    // the lane's NPX matching pixels of block b start at the lowest position it needs
+    auto pos0 = [&](int b) { return 1 + WIN * b + pr + disp[0] - (DS < 0 ? LPL - 1 : 0); };
+    auto load_block = [&](f32x2 (&pm)[NPX], float (&rv)[WIN], int b) {
+        const f32x2 *mp = ml + (pos0(b) - M0);
+        const float *rp = rl + (1 + WIN * b + pr - R0);
+#pragma unroll
+        for (int j = 0; j < NPX; j++)
+            pm[j] = mp[j];
+#pragma unroll
+        for (int s = 0; s < WIN; s++)
+            rv[s] = rp[s];
+    };
+    // one block of interior steps
+    auto fast_block = [&](const f32x2 (&pm)[NPX], const float (&rv)[WIN]) {
+#pragma unroll
+        for (int s = 0; s < WIN; s++) {
+#pragma unroll
+            for (int i = 0; i < LPL; i++) {
+                float c = dist(rv[s], pm[s + (DS < 0 ? LPL - 1 - i : i)]);
+                acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
+                ring[i][s] = c;
+            }
+            if (!(ABL & 1))
+                put(lane_off, tb + s * xsb, acc);
+        }
+        tb += WIN * xsb;
+    };
+    // one block whose matching positions may leave the row (its reference positions do not): the same
+    // walk with clamped pixel fetches, `outside` for the invalid ones and stores switched off per lane
+    auto edge_block = [&](int b) {
+        const int xb = 1 + WIN * b, p0 = pos0(b);
+        f32x2 pm[NPX];
+        bool ok[NPX];
+        float rv[WIN];
+#pragma unroll
+        for (int j = 0; j < NPX; j++) {
+            ok[j] = (unsigned)(p0 + j) < (unsigned)W;
+            pm[j] = ml[clampi(p0 + j, W) - M0];
+        }
+#pragma unroll
+        for (int s = 0; s < WIN; s++)
+            rv[s] = rl[xb + s + pr - R0];
+#pragma unroll
+        for (int s = 0; s < WIN; s++) {
+#pragma unroll
+            for (int i = 0; i < LPL; i++) {
+                const int j = s + (DS < 0 ? LPL - 1 - i : i);
+                float c = ok[j] ? dist(rv[s], pm[j]) : outf;
+                acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
+                ring[i][s] = c;
+            }
+            if (!(ABL & 1))
+                put((keep_all || lane_live(xb + s)) ? lane_off : oob, tb + s * xsb, acc);
+        }
+        tb += WIN * xsb;
+    };
+    // the general walk (blocks at the right end of the row, where the reference position is clamped)
+    auto general_block = [&](int b) {
+        const int xb = 1 + WIN * b;
+#pragma unroll
+        for (int s = 0; s < WIN; s++) {
+            const int x = xb + s;
+            if (x < W) {
+                const int xr = min(x + pr, W - 1);
+#pragma unroll
+                for (int i = 0; i < LPL; i++) {
+                    float c = cost(xr, i);
+                    acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
+                    ring[i][s] = c;
+                }
+                if (!((ABL & 1) && x + 2 < W))
+                    put((keep_all || lane_live(x)) ? lane_off : oob, tb + s * xsb, acc);
+            }
+        }
+        tb += WIN * xsb;
+    };
+
+    Geo g = geometry(0);
+    fetch(g);
+    for (int c0 = 0; c0 < nblocks || c0 == 0; c0 += cb) {
+        const int c1 = min(c0 + cb, nblocks);
+        if (c0 > 0)
+            __syncthreads();                           // everybody has left the previous chunk
+        commit(g);
+        R0 = g.R0;
+        M0 = g.M0;
+        __syncthreads();
+        if (c0 + cb < nblocks) {                       // the next chunk's bytes travel while this one is worked on
+            g = geometry(c0 + cb);
+            fetch(g);
+        }
+
+        if (c0 == 0) {                                 // x = 0: the window sum itself (BoxFilter.cpp:92-107)
+#pragma unroll
+            for (int i = 0; i < LPL; i++)
+                acc[i] = 0;
+#pragma unroll
+            for (int j = 0; j < WIN; j++) {
+                const int xr = clampi(pl + 1 + j, W);
+#pragma unroll
+                for (int i = 0; i < LPL; i++) {
+                    float c = cost(xr, i);
+                    ring[i][j] = c;
+                    acc[i] += scale * mag(c);
+                }
+            }
+            put(lane_off, 0, acc);
+            tb = xsb;                                  // tb = offset of step x = 1 + WIN * b from here on
+        }
+
+        int b = c0;
+        while (b < c1) {
+            if (b >= b_int0 && b < b_int1) {
+                const int be = min(c1, b_int1);        // interior blocks are one interval: [b, be) here
+                f32x2 mA[NPX], mB[NPX];
+                float rA[WIN], rB[WIN];
+                load_block(mA, rA, b);
+                for (; b + 2 <= be; b += 2) {          // two blocks per trip: the ring and the LDS
+                    load_block(mB, rB, b + 1);         // prefetch alternate between two register sets
+                    fast_block(mA, rA);
+                    if (b + 2 < be)
+                        load_block(mA, rA, b + 2);
+                    fast_block(mB, rB);
+                }
+                if (b < be) {
+                    fast_block(mA, rA);
+                    b++;
+                }
+            } else if (b < b_edge) {
+                edge_block(b);
+                b++;
+            } else {
+                general_block(b);
+                b++;
+            }
+        }
+    }
+}
+
+}  // namespace smk
