@@ -4,20 +4,23 @@
 N = 1 (BASELINE.json configs[2], the configuration the metric's target is quoted on):
     synthetic rectified pair 1920x1080, b = 1, D = 256, BT-interpolated SAD
     (match_fn 1, match_interval 1, match_max 1000), 9x9 box aggregation, PadCosts, WTA.
-N > 1: weak scaling by disparity slab -- every rank runs the same 256-level slab size on the
-    same image pair, the problem has D = 256*N levels, and the per-pixel (cost, d) keys are
-    min-reduced with ONE RCCL all-reduce (int64 MIN) per step, then decoded.  Steps are frames
-    of a stream: the all-reduce of frame i runs under the kernels of frame i + 1
-    (sharding.KeyReducePipeline, two key buffers); every frame is reduced and decoded inside
-    the timed region.
+N > 1 (BASELINE.json configs[4], the volume north_star asks the 1 -> 8 GPU scaling on):
+    synthetic 7680x4320 pair, D = 1024 in all, STRONG scaling by disparity slab -- rank r owns levels
+    sharding.slab_bounds(1024, N, r), runs them in fused calls of at most 256 levels (their keys are
+    min-merged locally), and the per-pixel (cost, d) keys of all ranks are min-reduced with ONE RCCL
+    all-reduce (int64 MIN, 265 MB) per frame, then decoded.  Steps are frames of a stream: the
+    all-reduce of frame i runs under the kernels of frame i + 1 (sharding.KeyReducePipeline, two key
+    buffers); every frame is reduced and decoded inside the timed region.
+    (--weak restores round 1's weak-scaling mode: config 3's frame, 256 levels per rank.)
 
 A step = one pass of the hot path over the resident image pair (images already in HBM).
 value = (W*H*D_total voxels of all ranks) / (max-over-ranks wall time of K steps).
 
 The JSON line also carries `roofline` (dominant kernel, HIP events recorded inside the timed
 region on the launch stream), `roofline_fused` (both passes against the 8N + images + outputs
-algorithmic bytes of SURVEY 8d) and `cpu_baseline` (the CPU oracle on one host core, on a
-bounded sample of the same workload; rank 0, N = 1 only).
+algorithmic bytes of SURVEY 8d), at N = 1 `cpu_baseline` (the CPU oracle on one host core, on the same
+workload; rank 0) and `verified_vs_oracle` (the frame left by the timed loop equals the oracle's), at
+N > 1 the per-rank compute time and the collective time left exposed.
 """
 import argparse
 import json
@@ -29,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+MAX_CALL_LEVELS = 256   # levels per fused call at N > 1 (bounds the slab workspace: 34 GB at 8K)
 
 
 def main():
@@ -36,21 +40,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--disp-per-gpu", type=int, default=256)
+    ap.add_argument("--width", type=int, default=0, help="default: 1920 at N = 1, 7680 at N > 1")
+    ap.add_argument("--height", type=int, default=0, help="default: 1080 at N = 1, 4320 at N > 1")
+    ap.add_argument("--disp-total", type=int, default=0, help="levels of the whole problem (default 256 / 1024)")
+    ap.add_argument("--disp-per-gpu", type=int, default=256, help="levels per rank in --weak mode")
+    ap.add_argument("--weak", action="store_true", help="N > 1: weak scaling of config 3 (256 levels per rank)")
     ap.add_argument("--window", type=int, default=9)
     ap.add_argument("--bands", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the short config 4 / config 5 measurements reported under 'extra'")
-    ap.add_argument("--cpu-rows", type=int, default=1080,
-                    help="rows of the workload the CPU baseline is timed on")
+    ap.add_argument("--cpu-rows", type=int, default=0,
+                    help="rows of the workload the CPU baseline is timed on (default: all)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the "
-                         "N > 1 code path where the ranks cannot have a GPU each)")
+                         "N > 1 code path where the ranks cannot have a GPU each: keys are then reduced "
+                         "through pinned host memory)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--check-oracle", action="store_true",
+                    help="rehearsal / test: rank 0 compares EVERY decoded frame with the CPU oracle")
+    ap.add_argument("--max-call-levels", type=int, default=MAX_CALL_LEVELS,
+                    help="N > 1: levels per fused call (tests lower it to exercise the local key merge)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")
     args = ap.parse_args()
@@ -78,9 +89,18 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    W, H, b, win = args.width, args.height, args.bands, args.window
-    Dg = args.disp_per_gpu
-    D = Dg * world
+    sharded = world > 1 and not args.weak          # config 5, strong scaling
+    max_call = args.max_call_levels
+    b, win = args.bands, args.window
+    W = args.width or (7680 if sharded else 1920)
+    H = args.height or (4320 if sharded else 1080)
+    if sharded:
+        D = args.disp_total or 1024
+        d_first, Dg = sharding.slab_bounds(D, world, rank)
+    else:
+        Dg = args.disp_total or args.disp_per_gpu
+        D = Dg * world
+        d_first = rank * Dg
     left, right, _ = synth.scene_pair(W, H, min(D, 256), n_bands=b)
 
     ctx = capi.Context(local_rank)
@@ -90,24 +110,56 @@ def main():
     stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(stream)
     ctx.set_stream(stream.cuda_stream)
+
+    extra = None
+    if world == 1 and not args.no_extra and rank == 0:
+        # the side measurements (configs 4 and 5 per GPU) run first: they also bring the device out of
+        # its idle power state before the W warm-up steps
+        extra = extra_configs(np, capi, synth, ctx)
+
     t_ref = torch.from_numpy(left.reshape(H, W * b)).to(dev)
     t_mtc = torch.from_numpy(right.reshape(H, W * b)).to(dev)
     keys = torch.empty((W, H), dtype=torch.int64, device=dev)   # column-major key image
     keys2 = torch.empty_like(keys) if world > 1 else None
+    keys_part = torch.empty_like(keys) if Dg > max_call and world > 1 else None
     disp = torch.empty((H, W), dtype=torch.int32, device=dev)
     best = torch.empty((H, W), dtype=torch.float32, device=dev)
     p = capi.match_params(W, H, b, D, match_fn=1, match_interval=1, match_max=1000)
-    d_first = rank * Dg
+    calls_per_step = 1 if world == 1 else (Dg + max_call - 1) // max_call
+
+    want = None
+    if args.check_oracle and rank == 0:
+        want = oracle_frame(np, left, right, D, win)
+    frames_checked = [0]
+    produce_events = []
 
     def produce(buf, _frame):
-        ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, d_first, Dg,
-                               buf.data_ptr())
+        if world == 1:
+            ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, d_first, Dg, buf.data_ptr())
+            return
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        if True:
+            for i, s0 in enumerate(range(d_first, d_first + Dg, max_call)):
+                n = min(max_call, d_first + Dg - s0)
+                out = buf if i == 0 else keys_part
+                ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, s0, n, out.data_ptr())
+                if i > 0:
+                    torch.minimum(buf, keys_part, out=buf)      # keys of one rank's calls merge like those of ranks
+        ev1.record()
+        produce_events.append((ev0, ev1))
 
     def consume(buf, _frame):
         ctx.keys_decode(buf.data_ptr(), W, H, disp.data_ptr(), best.data_ptr())
+        if want is not None:
+            got_d, got_b = disp.cpu().numpy(), best.cpu().numpy()
+            if not (np.array_equal(got_d, want[0]) and np.array_equal(got_b.view(np.uint32), want[1].view(np.uint32))):
+                raise SystemExit("frame %d differs from the oracle" % frames_checked[0])
+            frames_checked[0] += 1
 
     # N > 1: the one exchange step (int64 MIN all-reduce over xGMI) overlaps the next frame
-    pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume) if world > 1 else None
+    pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume,
+                                      host_staging=(args.backend != "nccl")) if world > 1 else None
 
     trace = bool(os.environ.get("BENCH_TRACE"))
 
@@ -129,76 +181,112 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    del produce_events[:]
     profiling = not os.environ.get("BENCH_NO_PROFILE")       # rehearsal aid
     if profiling:
-        ctx.profile_begin(args.steps)
+        ctx.profile_begin(args.steps * calls_per_step)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     dt = time.perf_counter() - t0
+    per_call = ctx.profile_get(0, args.steps * calls_per_step) if profiling else ([0.001], [0.001])
     n_prof, ms_a, ms_b = ctx.profile_end() if profiling else (1, 0.001, 0.001)
+    compute_ms = (sum(e0.elapsed_time(e1) for e0, e1 in produce_events) / len(produce_events) if produce_events
+                  else (ms_a + ms_b) / max(1, n_prof))
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, compute_ms], dtype=torch.float64, device="cpu" if args.backend != "nccl" and world > 1 else dev)
+    per_rank_compute = [compute_ms]
     if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        dt = max(float(g[0]) for g in gathered)
+        per_rank_compute = [round(float(g[1]), 4) for g in gathered]
 
     n_vox_gpu = W * H * Dg
-    n_vox = n_vox_gpu * world
+    n_vox = W * H * D
     value = n_vox * args.steps / dt / 1e9
     ms_step = dt / args.steps * 1e3
 
     if rank == 0:
         # algorithmic bytes per launch: pass A writes the slab once and reads the
         # images; pass B reads the slab once and writes one 8-byte key per pixel.
+        n_call = n_vox_gpu / calls_per_step             # voxels of one fused call
         n_bt = 3 if p.match_interval else 2          # ref + (mn, mx) or ref + match
-        bytes_a = 4.0 * n_vox_gpu + n_bt * b * W * H
-        bytes_b = 4.0 * n_vox_gpu + 8.0 * W * H
-        bytes_fused = 8.0 * n_vox_gpu + 2.0 * b * W * H + 8.0 * W * H
+        bytes_a = 4.0 * n_call + n_bt * b * W * H
+        bytes_b = 4.0 * n_call + 8.0 * W * H
+        bytes_fused = 8.0 * n_call + 2.0 * b * W * H + 8.0 * W * H
         ta, tb = ms_a / n_prof * 1e-3, ms_b / n_prof * 1e-3
-        traffic = {}
-        if os.path.exists(args.traffic_json):
+        traffic, traffic_source = {}, None
+        config3 = world == 1 and (W, H, Dg, b, win) == (1920, 1080, 256, 1, 9)
+        if config3 and os.path.exists(args.traffic_json):    # counters were collected on config 3 only
             with open(args.traffic_json) as f:
                 traffic = json.load(f)
+            traffic_source = traffic.get("source", "rocprofv3 --pmc passes of an earlier run of this command "
+                                                   "(profiles/README.md), not of this run")
 
-        def roof(name, nbytes, secs):
+        def stats(xs):
+            xs = sorted(xs)
+            return {"min": round(xs[0], 4), "median": round(xs[len(xs) // 2], 4), "max": round(xs[-1], 4)}
+
+        def roof(name, nbytes, secs, per=None):
             ach = nbytes / secs / 1e9
-            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic.get(name), "avg_ms": round(secs * 1e3, 4),
-                    "algorithmic_bytes": int(nbytes)}
-        ka = roof("fused_rawbox_h_lds_kernel", bytes_a, ta)
-        kb = roof("fused_boxv_wta_vpl_kernel", bytes_b, tb)
+            r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                 "traffic": traffic.get(name), "avg_ms": round(secs * 1e3, 4),
+                 "algorithmic_bytes": int(nbytes)}
+            if per:
+                r["ms_per_launch"] = stats(per)
+            return r
+        one_band_unit = b == 1                       # the float-lane pass A covers it (window 5..11)
+        name_a = "fused_rawbox_h_f_kernel" if one_band_unit and win in (5, 7, 9, 11) else "fused_rawbox_h_lds_kernel"
+        ka = roof(name_a, bytes_a, ta, per_call[0])
+        kb = roof("fused_boxv_wta_vpl_kernel", bytes_b, tb, per_call[1])
         dominant = ka if ta >= tb else kb
         fused = roof("fused pair (pass A + pass B)", bytes_fused, ta + tb)
 
+        if sharded:
+            workload = ("fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, D=%d over %d GPUs by "
+                        "disparity slab (%d levels per GPU in calls of <= %d), int64-MIN %s all-reduce of the keys" % (
+                            win, win, W, H, b, D, world, Dg, max_call,
+                            "RCCL" if args.backend == "nccl" else args.backend + " (host-staged)"))
+        else:
+            workload = "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, D=%d (%d levels per GPU%s)" % (
+                win, win, W, H, b, D, Dg,
+                ", int64-MIN %s all-reduce of keys" % ("RCCL" if args.backend == "nccl" else args.backend)
+                if world > 1 else "")
         out = {
             "metric": "cost-volume throughput (G pixel*disparity/s)",
             "value": round(value, 2), "unit": "G pixel*disparity/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, "
-                            "D=%d (%d levels per GPU%s)" % (
-                                win, win, W, H, b, D, Dg,
-                                ", int64-MIN %s all-reduce of keys" % ("RCCL" if args.backend == "nccl" else args.backend)
-                                if world > 1 else ""),
+                "workload": workload,
                 "width": W, "height": H, "bands": b, "disp_total": D, "disp_per_gpu": Dg,
                 "window": win, "match_fn": "AD", "match_interval": 1, "match_max": 1000,
                 "parallelism": "disparity slabs x%d" % world,
                 "collective_backend": (args.backend if world > 1 else None)},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernel": dominant["kernel"],
+            "traffic_source": traffic_source,
             "roofline_fused": fused,
             "kernels": [ka, kb],
         }
-        if world == 1 and not args.no_extra:
-            out["extra"] = extra_configs(np, capi, synth, ctx)
+        if world > 1:
+            out["per_rank_compute_ms"] = per_rank_compute
+            out["exposed_collective_ms"] = round(ms_step - max(per_rank_compute), 4)
+            out["collective_bytes_per_step"] = W * H * 8
+        if args.check_oracle:
+            out["frames_checked_vs_oracle"] = frames_checked[0]
+        if extra is not None:
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(np, left, right, args, Dg, win)
-            out["cpu_baseline_all_cores"] = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
+            got = (disp.cpu().numpy(), best.cpu().numpy())         # the frame the timed loop left behind
+            out["cpu_baseline"], ok = cpu_baseline(np, left, right, args, Dg, win, got=got)
+            out["verified_vs_oracle"] = ok
+            out["cpu_baseline_all_cores"], _ = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
             if "extra" in out:
                 out["extra"]["config4_cpu"] = cpu_config4(np, synth)
         print(json.dumps(out), flush=True)
@@ -207,6 +295,17 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def oracle_frame(np, left, right, D, win):
+    from oracle import oracle as O
+    O.use_openmp(True)
+    h, w, b = left.shape
+    p = O.make_params(w, h, b, disp_min=0, disp_max=D - 1, match_fn=1, match_interval=1, match_max=1000,
+                      aggr_window_size=win)
+    d, c = O.compute_correspondence(left, right, p)[:2]
+    O.use_openmp(False)
+    return d, c
 
 
 def extra_configs(np, capi, synth, ctx):
@@ -283,14 +382,14 @@ def extra_configs(np, capi, synth, ctx):
     return res
 
 
-def cpu_baseline(np, left, right, args, D, win, openmp=False):
+def cpu_baseline(np, left, right, args, D, win, openmp=False, got=None):
     """The CPU oracle (a port of the reference's single-threaded CPU path, bit-identical to it on
     the tsukuba anchors) on the top `cpu_rows` rows of the same image pair: one core (like the
     reference), or -- openmp=True -- the -fopenmp build of the same source on the host cores this
     process may use (OMP_NUM_THREADS)."""
     from oracle import oracle as O
     O.use_openmp(openmp)
-    rows = min(args.cpu_rows, left.shape[0])
+    rows = min(args.cpu_rows or left.shape[0], left.shape[0])
     l, r = np.ascontiguousarray(left[:rows]), np.ascontiguousarray(right[:rows])
     h, w, b = l.shape
     p = O.make_params(w, h, b, disp_min=0, disp_max=D - 1, match_fn=1, match_interval=1,
@@ -298,16 +397,20 @@ def cpu_baseline(np, left, right, args, D, win, openmp=False):
     O.lib()
     cores = O.threads()
     t0 = time.perf_counter()
-    O.compute_correspondence(l, r, p)
+    res = O.compute_correspondence(l, r, p)
     dt = time.perf_counter() - t0
     O.use_openmp(False)
+    verified = None
+    if got is not None and rows == left.shape[0]:    # the device's frame against the one just computed here
+        verified = bool(np.array_equal(got[0], res[0]) and
+                        np.array_equal(got[1].view(np.uint32), res[1].view(np.uint32)))
     return {"value": round(w * h * D / dt / 1e9, 5), "unit": "G pixel*disparity/s", "cores": cores,
             "kind": "port",
             "sample": "top %d of %d rows of the same %dx%d D=%d pair (%.1f s wall); "
                       "oracle/sm_oracle.c, gcc -O2%s" % (
                           rows, left.shape[0], w, left.shape[0], D, dt,
                           " -fopenmp, rows / column blocks over %d threads" % cores if openmp
-                          else ", single thread like the reference")}
+                          else ", single thread like the reference")}, verified
 
 
 def cpu_config4(np, synth):

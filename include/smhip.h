@@ -63,8 +63,24 @@ typedef struct smhip_match_params {
 int smhip_init(int device, smhip_ctx **ctx);
 int smhip_shutdown(smhip_ctx *ctx);
 const char *smhip_last_error(void);
-/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream */
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = null stream.
+ * The context's workspaces are shared by all its calls whatever stream they ran on, so changing the
+ * stream first waits for the work queued on the old one. */
 int smhip_set_stream(smhip_ctx *ctx, void *hip_stream);
+/* Tuning / test knobs of a context (no counterpart in the reference; nothing in the library reads the
+ * environment).  value < 0 restores the library's own policy.  Waits for the context's queued work. */
+enum smhip_option {
+    SMHIP_OPT_NARROW = 0,     /* 1: general-shape fused kernels for slabs of <= 32 levels */
+    SMHIP_OPT_TYSHIFT,        /* log2 of the band height of the fused path's private slab, 0..8 */
+    SMHIP_OPT_CHUNK,          /* 1 / 0: pass A stages rows in chunks / whole (integer kernels) */
+    SMHIP_OPT_BT_PREPASS,     /* 1: Birchfield-Tomasi intervals from the pre-pass kernel, always */
+    SMHIP_OPT_TSEG,           /* rows per workgroup of the LDS-tiled filters, 8..4096 */
+    SMHIP_OPT_MAXK,           /* iterations per pass of the multi-iteration filters, 1..4 */
+    SMHIP_OPT_FLOAT_A,        /* 0: pass A by the integer kernels also where the float-lane kernel applies */
+    SMHIP_OPT_KEYBUF,         /* key groups (of ~64 rows) pass B collects in LDS before it stores them; 0: none */
+    SMHIP_OPT_COUNT
+};
+int smhip_set_option(smhip_ctx *ctx, int option, int value);
 int smhip_sync(smhip_ctx *ctx);
 /* bytes of device workspace the context currently holds (temporaries of the filters) */
 size_t smhip_workspace_bytes(const smhip_ctx *ctx);
@@ -265,6 +281,8 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
  * (raw cost + horizontal running sum) and pass B (vertical running sum + pad + WTA). */
 int smhip_profile_begin(smhip_ctx *ctx, int max_calls);
 int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_pass_b);
+/* per-call times of the profiled calls [first, first + count) (waits for the stream); before _end */
+int smhip_profile_get(smhip_ctx *ctx, int first, int count, float *ms_pass_a, float *ms_pass_b);
 
 #ifdef __cplusplus
 }

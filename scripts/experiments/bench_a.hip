@@ -1,8 +1,8 @@
 // bench_a.hip -- pass A variants on config 3's shape (and the 128-level slab shape): timing and a
 // bit-for-bit comparison of the slab T with the one-level-per-lane kernel.  GPU box only.
-#include "../stereomatch_amd/csrc/smhip_fused_ps.h"
-#include "../stereomatch_amd/csrc/smhip_fused_f.h"
-#include "../stereomatch_amd/csrc/smhip_fused_bf.h"
+#include "smhip_fused_ps.h"
+#include "../../stereomatch_amd/csrc/smhip_fused_f.h"
+#include "smhip_fused_bf.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>

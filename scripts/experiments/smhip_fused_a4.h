@@ -11,7 +11,7 @@
 // Arithmetic and operation order per chain are those of fused_rawbox_h_lds_kernel (bit-identical T).
 #pragma once
 
-#include "smhip_fused_b.h"   // vecf
+#include "../../stereomatch_amd/csrc/smhip_fused_b.h"   // vecf
 
 namespace smk {
 

@@ -19,7 +19,7 @@
 // and the key folds -0 into +0 as ordered_bits does.
 #pragma once
 
-#include "smhip_fused_b.h"
+#include "../../stereomatch_amd/csrc/smhip_fused_b.h"
 
 #pragma clang diagnostic ignored "-Winline-asm"   // the M0 clobber below
 

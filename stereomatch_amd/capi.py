@@ -4,6 +4,7 @@ This is plumbing for Python callers (tests, bench.py); the compute is entirely i
 HIP library.  There is no CPU fallback: if the library is missing or a call fails, an
 exception is raised.
 """
+import contextlib
 import ctypes as C
 import os
 
@@ -14,13 +15,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libsmhip.so")
 
 # every symbol include/smhip.h declares
 SYMBOLS = [
-    "smhip_init", "smhip_shutdown", "smhip_last_error", "smhip_set_stream", "smhip_sync",
+    "smhip_init", "smhip_shutdown", "smhip_last_error", "smhip_set_stream", "smhip_set_option", "smhip_sync",
     "smhip_workspace_bytes", "smhip_malloc", "smhip_free", "smhip_memcpy_h2d",
     "smhip_memcpy_d2h", "smhip_memcpy_d2d", "smhip_memcpy2d_h2d", "smhip_memcpy2d_d2h", "smhip_match_outside",
     "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_min_filter_to",
     "smhip_convolve_14641", "smhip_convolve_14641_to",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
-    "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end",
+    "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end", "smhip_profile_get",
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
@@ -101,6 +102,7 @@ def load():
     L.smhip_last_error.restype = C.c_char_p
     L.smhip_last_error.argtypes = []
     L.smhip_set_stream.argtypes = [vp, vp]
+    L.smhip_set_option.argtypes = [vp, ci, ci]
     L.smhip_sync.argtypes = [vp]
     L.smhip_workspace_bytes.restype = sz
     L.smhip_workspace_bytes.argtypes = [vp]
@@ -140,6 +142,7 @@ def load():
     L.smhip_opt_dp.argtypes = [vp, vp, ci, ci, ci, sz, vp, sz, ci, cf, cf, cf, ci, vp, vp]
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
+    L.smhip_profile_get.argtypes = [vp, ci, ci, C.POINTER(cf), C.POINTER(cf)]
     for name in SYMBOLS:
         f = getattr(L, name)
         if name not in ("smhip_last_error", "smhip_workspace_bytes", "smhip_match_outside"):
@@ -174,6 +177,10 @@ def _ptr(x):
     return int(x)
 
 
+# enum smhip_option (include/smhip.h)
+OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7}
+
+
 class Context:
     """One device context (`smhip_ctx`); not thread-safe, like the reference."""
 
@@ -199,6 +206,21 @@ class Context:
 
     def sync(self):
         self._chk(self.L.smhip_sync(self.h))
+
+    def set_option(self, name, value):
+        """Tuning / test knob of this context (`enum smhip_option`); value < 0 = the library's policy."""
+        self._chk(self.L.smhip_set_option(self.h, OPTIONS[name], int(value)))
+
+    @contextlib.contextmanager
+    def options(self, **kw):
+        """`with ctx.options(chunk=1, tyshift=3): ...` -- knobs set for the block, policy restored after."""
+        try:
+            for k, v in kw.items():
+                self.set_option(k, v)
+            yield self
+        finally:
+            for k in kw:
+                self.set_option(k, -1)
 
     def workspace_bytes(self):
         return self.L.smhip_workspace_bytes(self.h)
@@ -361,6 +383,12 @@ class Context:
 
     def profile_begin(self, max_calls):
         self._chk(self.L.smhip_profile_begin(self.h, max_calls))
+
+    def profile_get(self, first, count):
+        """Per-call (ms of pass A, ms of pass B) lists of the profiled calls [first, first + count)."""
+        a, b = (C.c_float * count)(), (C.c_float * count)()
+        self._chk(self.L.smhip_profile_get(self.h, first, count, a, b))
+        return list(a), list(b)
 
     def profile_end(self):
         """Returns (n_calls, total ms of pass A, total ms of pass B)."""

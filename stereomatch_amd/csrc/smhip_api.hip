@@ -4,6 +4,7 @@
 #include "smhip_fused.h"
 #include "smhip_fused_b.h"
 #include "smhip_fused_chunk.h"
+#include "smhip_fused_f_launch.h"
 #include "smhip_stencil.h"
 #include "smhip_subpix.h"
 #include "smhip_stage.h"
@@ -54,6 +55,7 @@ struct smhip_ctx {
     double *bayes_w, *bayes_wh;          // AggrBayesian weights: device copy, host copy
     int bayes_n, bayes_band;             // levels they were computed for (0: none), half band width
     float bayes_sigma, bayes_eps;
+    int opt[SMHIP_OPT_COUNT];            // smhip_set_option; -1 = the library's own policy
 };
 
 namespace {
@@ -240,7 +242,23 @@ int smhip_init(int device, smhip_ctx **out)
         return fail(SMHIP_ENOMEM, "out of host memory");
     ctx->device = device;
     ctx->stream = nullptr;
+    for (int i = 0; i < SMHIP_OPT_COUNT; i++)
+        ctx->opt[i] = -1;
     *out = ctx;
+    return SMHIP_OK;
+}
+
+int smhip_set_option(smhip_ctx *ctx, int option, int value)
+{
+    if (!ctx)
+        return fail(SMHIP_EINVAL, "null context");
+    if (option < 0 || option >= SMHIP_OPT_COUNT)
+        return fail(SMHIP_EINVAL, "unknown option %d", option);
+    if (option == SMHIP_OPT_TYSHIFT && value > 8)
+        return fail(SMHIP_EINVAL, "slab band shift %d outside 0..8", value);
+    // the slab layout and the kernels of calls already queued must not change under them
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->opt[option] = value < 0 ? -1 : value;
     return SMHIP_OK;
 }
 
@@ -268,6 +286,10 @@ int smhip_set_stream(smhip_ctx *ctx, void *hip_stream)
 {
     if (!ctx)
         return fail(SMHIP_EINVAL, "null context");
+    // The workspaces (slab, interval images, partial keys) belong to the context, not to a stream: work
+    // queued on the old stream may still be reading them, so the old stream is drained first.
+    if ((hipStream_t)hip_stream != ctx->stream)
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     return SMHIP_OK;
 }
@@ -489,13 +511,10 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
 
 // Rows per workgroup of the tile kernels: 128 for large volumes (6 % re-computed halo rows), down
 // to 16 for small ones so that a launch still has on the order of a thousand workgroups.
-static int tile_seglen(int w, int h, int nb)
+static int tile_seglen(const smhip_ctx *ctx, int w, int h, int nb)
 {
-    if (const char *e = getenv("SMHIP_TSEG")) {      // test knob: force a segment length
-        int v = atoi(e);
-        if (v >= 8 && v <= 4096)
-            return v;
-    }
+    if (ctx->opt[SMHIP_OPT_TSEG] >= 8 && ctx->opt[SMHIP_OPT_TSEG] <= 4096)   // forced segment length
+        return ctx->opt[SMHIP_OPT_TSEG];
     long tiles = (long)((w + 31) / 32) * ((nb + 31) / 32);
     int seg = 128;
     while (seg > 16 && tiles * ((h + seg - 1) / seg) < 2048)
@@ -532,7 +551,7 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
             smk::minfilter_walk_kernel<1, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
                                                                             row_elems, seglen);     \
     } while (0)
-    const int tseg = tile_seglen(w, h, nb);
+    const int tseg = tile_seglen(ctx, w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
 #define LAUNCH_TMIN(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32><<<tgrid, 256, 0, ctx->stream>>>( \
         d_src, d_dst, w, nb, h, row_elems, tseg)
@@ -613,7 +632,7 @@ int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, in
     const int seglen = 64;
     int vec = walk_vec(nb, row_elems, d_src, d_dst, nullptr);
     dim3 grid = walk_grid(w, nb, h, vec, seglen);
-    const int tseg = tile_seglen(w, h, nb);
+    const int tseg = tile_seglen(ctx, w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
     if (vec == 4 && tgrid.y <= 65535 && tgrid.z <= 65535)
         smk::tile_walk_kernel<smk::BinomOp, 32><<<tgrid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h,
@@ -680,14 +699,11 @@ static int multi_depth(int remaining, int passes_left)
 // x4 with 16 levels 0.37 ms at depth 4, 0.25 ms one by one; 32..64 levels depth 2 beats depth 4 by
 // 3..11 %, 3840x2160x64 (2.1 GB) is back at depth 4 (1.68 against 1.87 ms); diffusion x10 with 16
 // levels 0.39 -> 0.32 ms at depth 2, but 384x288x16 0.084 (depth 4) against 0.088 ms; from 32 levels
-// on, and for the config-4 volume (17 GB), depth 4 wins.  SMHIP_MAXK forces a depth (tests).
-static int multi_maxk(bool binomial, int nb, size_t volume_bytes)
+// on, and for the config-4 volume (17 GB), depth 4 wins.  SMHIP_OPT_MAXK forces a depth (tests).
+static int multi_maxk(const smhip_ctx *ctx, bool binomial, int nb, size_t volume_bytes)
 {
-    if (const char *e = getenv("SMHIP_MAXK")) {
-        int k = atoi(e);
-        if (k >= 1 && k <= 4)
-            return k;
-    }
+    if (ctx->opt[SMHIP_OPT_MAXK] >= 1 && ctx->opt[SMHIP_OPT_MAXK] <= 4)
+        return ctx->opt[SMHIP_OPT_MAXK];
     if (binomial)
         return nb <= 16 ? 1 : (volume_bytes < ((size_t)1 << 30) ? 2 : 4);
     return (nb <= 16 && volume_bytes > ((size_t)32 << 20)) ? 2 : 4;   // tsukuba-size volumes: launches count, depth 4
@@ -709,7 +725,7 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
     const bool mem = beta > 0.0f;
     float *cur = d_a, *oth = d_b;
     *result_in_b = 0;
-    const int tseg = tile_seglen(w, h, nb);
+    const int tseg = tile_seglen(ctx, w, h, nb);
     const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
     if (walk_vec(nb, row_elems, d_a, d_b, mem ? d_cost0 : nullptr) != 4 || gy > 65535 || gz > 65535) {
         for (int i = 0; i < n_iter; i++) {          // unaligned shapes: one iteration per pass
@@ -722,7 +738,7 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
     }
     float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
     float lb = lambda * beta;            // :132
-    const int maxk = multi_maxk(false, nb, row_elems * (size_t)h * sizeof(float));
+    const int maxk = multi_maxk(ctx, false, nb, row_elems * (size_t)h * sizeof(float));
     int passes = (n_iter + maxk - 1) / maxk;
     for (int left = n_iter; left > 0; passes--) {
         int K = multi_depth(left, passes);
@@ -762,7 +778,7 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         return fail(SMHIP_EINVAL, "negative iteration count");
     float *cur = d_a, *oth = d_b;
     *result_in_b = 0;
-    const int tseg = tile_seglen(w, h, nb);
+    const int tseg = tile_seglen(ctx, w, h, nb);
     const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
     if (walk_vec(nb, row_elems, d_a, d_b, nullptr) != 4 || gy > 65535 || gz > 65535) {
         for (int i = 0; i < n_iter; i++) {
@@ -773,7 +789,7 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         }
         return SMHIP_OK;
     }
-    const int maxk = multi_maxk(true, nb, row_elems * (size_t)h * sizeof(float));
+    const int maxk = multi_maxk(ctx, true, nb, row_elems * (size_t)h * sizeof(float));
     int passes = (n_iter + maxk - 1) / maxk;
     for (int left = n_iter; left > 0; passes--) {
         int K = multi_depth(left, passes);
@@ -1190,7 +1206,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     int Dp, CH;
     const bool img_aligned = p->n_bands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
                                                  ((uintptr_t)d_mtc & 3) == 0);
-    if (d_count <= 32 && !(img_aligned && !getenv("SMHIP_NARROW"))) {
+    if (d_count <= 32 && !(img_aligned && ctx->opt[SMHIP_OPT_NARROW] != 1)) {
         Dp = 2;                      // general-shape kernels (4-band images with unaligned rows)
         while (Dp < d_count) Dp <<= 1;
         CH = Dp;
@@ -1214,22 +1230,23 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         return fail(SMHIP_EINVAL, "fused box -> DSI needs >= 33 levels, D %% 4 == 0 and 16-byte aligned rows");
     // banded slab layout (smhip_fused.h) only when both passes are the tuned kernels
     int tyshift = tuned_a ? 5 : 0;
-    if (const char *e = getenv("SMHIP_TYSHIFT")) { if (tuned_a) tyshift = atoi(e); }
-    if (tyshift < 0 || tyshift > 8)
-        return fail(SMHIP_EINVAL, "bad SMHIP_TYSHIFT");
+    if (tuned_a && ctx->opt[SMHIP_OPT_TYSHIFT] >= 0)
+        tyshift = ctx->opt[SMHIP_OPT_TYSHIFT];           // (smhip_set_option keeps it within 0..8)
     size_t bands = ((size_t)H + (1u << tyshift) - 1) >> tyshift;
     size_t trow = (size_t)W * Dp;                       // floats per image row of T
     size_t t_elems = (bands << tyshift) * trow;
 
     // pass A stages whole rows in LDS; rows above 40 KB (4 bands: wider than 2560 pixels) are staged
-    // chunk by chunk (smhip_fused_chunk.h); SMHIP_CHUNK=1/0 forces the choice in tests
+    // chunk by chunk (smhip_fused_chunk.h); SMHIP_OPT_CHUNK = 1 / 0 forces the choice in tests (and with
+    // it the integer kernels)
     bool chunked = (size_t)W * (p->n_bands == 1 ? 4 : 16) > 40 * 1024;
-    if (const char *e = getenv("SMHIP_CHUNK")) chunked = atoi(e) != 0;
+    const bool chunked_forced = ctx->opt[SMHIP_OPT_CHUNK] >= 0;
+    if (chunked_forced) chunked = ctx->opt[SMHIP_OPT_CHUNK] != 0;
     // one band, whole-row kernel: the matching row's Birchfield-Tomasi interval is formed while the row
     // is staged, so the pre-pass over the image (bt_minmax_kernel) and its workspace are not needed
-    // (bit-identical, 0.8 % faster per step); SMHIP_BT_PREPASS=1 keeps the pre-pass (tests)
+    // (bit-identical, 0.8 % faster per step); SMHIP_OPT_BT_PREPASS = 1 keeps the pre-pass (tests)
     const bool bt_inline = tuned_a && !chunked && p->n_bands == 1 && p->match_interval &&
-                           !p->match_interpolated && !getenv("SMHIP_BT_PREPASS");
+                           !p->match_interpolated && ctx->opt[SMHIP_OPT_BT_PREPASS] != 1;
 
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
@@ -1273,6 +1290,11 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "row staging needs %zu bytes of LDS (width %d, window %d, step %d)", lds, W,
                         window, adstep);
+        // one band, unit step, point reference interval, window 5..11: the float-lane kernel
+        // (smhip_fused_f.h, a translation unit of its own); everything else: the integer kernels below
+        const bool float_a = !chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0 &&
+            smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, CH / 64,
+                                         a.sd != 0, nbands * (a.sd ? 255 * 255 : 255), ctx->stream);
 #define LAUNCH_A3(WIN, SD, NB)                                                                           \
         do {                                                                                             \
             if (chunked) smk::fused_rawbox_h_chunk_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>(   \
@@ -1285,6 +1307,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
             else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \
         } while (0)
+        if (!float_a)
         switch (window) {            // static windows: the leaving cost comes from a register ring
         case 3: LAUNCH_A(3); break;
         case 5: LAUNCH_A(5); break;
@@ -1310,9 +1333,18 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         const int wpb = 4;
         int x_per_xcd = (W + 7) / 8;
         dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), keep_all ? (Dp + 255) / 256 : n_chunks);
-#define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, 0, ctx->stream>>>( \
+        // keys collect in a wave-private LDS buffer of kb_rows rows (a multiple of the kernel's key group)
+        // and go to memory in long runs: stores into the read stream cost HBM bus turn-arounds
+        const int kblk = (window == 3 || window == 5 || window == 7 || window == 9 || window == 11) ? window : 8;
+        const int kgrp = (64 / kblk) * kblk;
+        int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : 18;   // 0: unbuffered
+        if (kb_groups > (H + kgrp - 1) / kgrp) kb_groups = (H + kgrp - 1) / kgrp;
+        if (kb_groups > 64) kb_groups = 64;                 // 4 waves x 64 groups x 64 rows x 8 B = 128 KB
+        const int kb_rows = kgrp * kb_groups;
+        const size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long);
+#define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
-        d_first, x_per_xcd, kout, n_pix)
+        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
 #define LAUNCH_BW(WIN)                                 \
         switch (CH / 64) {                             \
         case 1: LAUNCH_BT(WIN, 1); break;              \
@@ -1385,7 +1417,11 @@ int smhip_fused_box_dsi(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
 {
     if (!p)
         return fail(SMHIP_EINVAL, "null argument");
-    int rc = check_dsi(d_cost, p->width, p->height, d_count > 0 ? d_count : 1, row_elems);
+    int rc = check_params(p, d_ref, d_mtc, img_pitch);
+    if (rc) return rc;
+    if (d_count < 1)
+        return fail(SMHIP_EINVAL, "disparity slab needs at least one level (d_count=%d)", d_count);
+    rc = check_dsi(d_cost, p->width, p->height, d_count, row_elems);
     if (rc) return rc;
     return fused_impl(ctx, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, nullptr, d_cost, row_elems);
 }
@@ -1405,7 +1441,7 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     int w = p->width, h = p->height;
     rc = check_dsi(d_cost, w, h, d_count, row_elems);
     if (rc) return rc;
-    const int tseg = tile_seglen(w, h, d_count);
+    const int tseg = tile_seglen(ctx, w, h, d_count);
     dim3 tgrid((w + 31) / 32, (d_count + 31) / 32, (h + tseg - 1) / tseg);
     if (walk_vec(d_count, row_elems, d_cost, nullptr, nullptr) != 4 || min_window % 2 != 1 || min_window < 3 ||
         min_window > 11 || tgrid.y > 65535 || tgrid.z > 65535)
@@ -1485,6 +1521,22 @@ int smhip_profile_begin(smhip_ctx *ctx, int max_calls)
     return SMHIP_OK;
 }
 
+int smhip_profile_get(smhip_ctx *ctx, int first, int count, float *ms_pass_a, float *ms_pass_b)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->ev)
+        return fail(SMHIP_EINVAL, "profiling not active");
+    if (first < 0 || count < 0 || first + count > ctx->ev_used || !ms_pass_a || !ms_pass_b)
+        return fail(SMHIP_EINVAL, "profiled calls [%d,%d) outside [0,%d)", first, first + count, ctx->ev_used);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < count; i++) {
+        HIP_TRY(hipEventElapsedTime(&ms_pass_a[i], ctx->ev[3 * (first + i)], ctx->ev[3 * (first + i) + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms_pass_b[i], ctx->ev[3 * (first + i) + 1], ctx->ev[3 * (first + i) + 2]));
+    }
+    return SMHIP_OK;
+}
+
 int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_pass_b)
 {
     int rc = check_ctx(ctx);
@@ -1520,6 +1572,8 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
         return fail(SMHIP_EINVAL, "null parameters");
     if (!d_disp && !d_best)
         return fail(SMHIP_EINVAL, "no output requested");
+    rc = check_params(p, d_ref, d_mtc, img_pitch);      // before any size is derived from p
+    if (rc) return rc;
     size_t n_pix = (size_t)p->width * p->height;
     // keys live behind the per-chunk partials in the key workspace
     int d_count = p->disp_n;

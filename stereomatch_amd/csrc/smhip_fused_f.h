@@ -29,7 +29,7 @@
 // inserts no wait state for this form.  dwordx2 / dword stores are not affected -- LPL stays <= 2 here.
 #pragma once
 
-#include "smhip_fused_b.h"
+#include "smhip_fused_defs.h"
 
 namespace smk {
 
@@ -43,7 +43,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 
 template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0>   // ABL: ablations of scripts/bench_a.hip
-__global__ __launch_bounds__(64 * NW) void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))   // two waves per SIMD exist at most
+void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
                                                                    int nref, int nmatch, int glev)
 {
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(64 * NW) void fused_rawbox_h_f_kernel(FusedA a, flo
                 ring[i][s] = c;
             }
             if (!(ABL & 1))
-                put((keep_all || lane_live(xb + s)) ? lane_off : oob, tb + s * xsb, acc);
+                put(lane_off + (-(int)!(keep_all || lane_live(xb + s)) & oob), tb + s * xsb, acc);   // (a ?: here became a table in scratch)
         }
         tb += WIN * xsb;
     };
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(64 * NW) void fused_rawbox_h_f_kernel(FusedA a, flo
                     ring[i][s] = c;
                 }
                 if (!((ABL & 1) && x + 2 < W))
-                    put((keep_all || lane_live(x)) ? lane_off : oob, tb + s * xsb, acc);
+                    put(lane_off + (-(int)!(keep_all || lane_live(x)) & oob), tb + s * xsb, acc);
             }
         }
         tb += WIN * xsb;

@@ -1,0 +1,68 @@
+// smhip_fused_f.hip -- instantiations and dispatch of the float-lane pass A (smhip_fused_f.h).
+// Built with -fno-slp-vectorize (see the header of smhip_fused_f.h) and linked into libsmhip.so.
+#include "smhip_fused_f.h"
+#include "smhip_fused_f_launch.h"
+
+namespace smk {
+
+namespace {
+
+template <int WIN, bool SD, bool CUT, int DS>
+void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
+                  hipStream_t stream)
+{
+    // 256-level chunks: two waves of two levels per lane; a 128-level slab: one wave
+    const int nw = Dp % 256 == 0 ? 2 : 1;
+    const int cw = 128 * nw;
+    int cbs = FUSED_F_NI * 64 * nw - WIN - cw;             // staged pixels per thread bounded by FUSED_F_NI
+    if (cbs > 480) cbs = 480;
+    const int cb = cbs / WIN, nref = cb * WIN + WIN, nmatch = nref + cw;
+    const size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
+    dim3 grid(a.H, Dp / cw);
+    if (nw == 2)
+        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2><<<grid, 128, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
+                                                                                   cb, nref, nmatch, glev);
+    else
+        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 1><<<grid, 64, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
+                                                                                  cb, nref, nmatch, glev);
+}
+
+template <int WIN>
+void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
+                   bool cut, hipStream_t stream)
+{
+#define SMK_F(SD, CUT)                                                                             \
+    do {                                                                                           \
+        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream); \
+        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream);      \
+    } while (0)
+    if (sd) { if (cut) SMK_F(true, true); else SMK_F(true, false); }
+    else    { if (cut) SMK_F(false, true); else SMK_F(false, false); }
+#undef SMK_F
+}
+
+}  // namespace
+
+bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
+                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream)
+{
+    if (n_bands != 1 || (a.dstep != 1 && a.dstep != -1) || a.rn != a.rx || Dp % 128 != 0)
+        return false;
+    if (glev != 2 && glev != 4)
+        return false;
+    // buffer-store offsets are 32-bit: the row's extent in the slab and twice that must fit
+    const unsigned long long extent = (unsigned long long)a.W * ((unsigned long long)Dp << tyshift) * 4ull;
+    if (extent >= (1ull << 31) || a.cutoff < 0 || a.cutoff >= (1 << 24))
+        return false;
+    const bool cut = a.cutoff < max_cost;                  // truncation can bite
+    switch (window) {
+    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
+    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
+    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
+    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
+    default: return false;
+    }
+    return true;
+}
+
+}  // namespace smk

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "smhip_fused_defs.h"
+
 namespace smk {
 
 // Parameters of the raw-cost evaluation, shared by the stand-alone and fused kernels.
@@ -29,7 +31,6 @@ struct RawArgs {
     int outside;                // m_match_outside as an integer (StcRawCosts.cpp:365-367)
 };
 
-__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
 // MatchLine, StcRawCosts.cpp:152-198 (den = 1): cost of reference pixel x at level k.
 __device__ __forceinline__ int raw_cost(const RawArgs &a, const uint8_t *rmn, const uint8_t *rmx,

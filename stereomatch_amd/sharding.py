@@ -63,17 +63,41 @@ class KeyReducePipeline:
     is not rewritten before its consumer ran.  Call flush() after the last frame.
     """
 
-    def __init__(self, key_buffers, produce, consume, group=None, force_collective=False):
+    def __init__(self, key_buffers, produce, consume, group=None, force_collective=False, host_staging=False):
         if len(key_buffers) != 2:
             raise ValueError("KeyReducePipeline needs exactly two key buffers")
         self.bufs, self.produce, self.consume, self.group = key_buffers, produce, consume, group
         self.force_collective = force_collective    # issue the all-reduce even in a group of one (tests)
+        # host_staging: the collective runs on a pinned CPU copy of the keys (copy out, all-reduce, copy
+        # back).  For the gloo backend with device key buffers: gloo's own device-tensor path stalls when
+        # two ranks share one GPU (scripts/gloo_probe.py), its CPU path does not.  No overlap in this mode.
+        self.host_staging = host_staging
+        self._host = None
         self.n = 0
         self.pending = None
+
+    class _StagedReduce:
+        """wait() = copy the keys to the host, all-reduce them there, copy them back (stream-ordered)."""
+
+        def __init__(self, pipe, buf):
+            self.pipe, self.buf = pipe, buf
+
+        def wait(self):
+            import torch
+            import torch.distributed as dist
+            p = self.pipe
+            if p._host is None or p._host.shape != self.buf.shape:
+                p._host = torch.empty(self.buf.shape, dtype=self.buf.dtype, device="cpu").pin_memory()
+            p._host.copy_(self.buf, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.all_reduce(p._host, op=dist.ReduceOp.MIN, group=p.group)
+            self.buf.copy_(p._host, non_blocking=True)
 
     def _reduce_async(self, buf):
         import torch.distributed as dist
         if dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.force_collective):
+            if self.host_staging and buf.is_cuda:
+                return KeyReducePipeline._StagedReduce(self, buf)
             return dist.all_reduce(buf, op=dist.ReduceOp.MIN, group=self.group, async_op=True)
         return None
 

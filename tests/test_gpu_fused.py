@@ -189,16 +189,16 @@ def test_exp2_pipeline_fused_equals_staged(gpu_ctx, oracle):
         assert np.array_equal(depth, odepth)
 
 
-def test_general_shape_narrow_kernels(gpu_ctx, oracle, monkeypatch):
+def test_general_shape_narrow_kernels(gpu_ctx, oracle):
     """The general-shape fused kernels (narrow slabs of 4-band images whose rows are not 4-byte
-    aligned) stay bit-identical to the oracle; SMHIP_NARROW forces them on an aligned input."""
-    monkeypatch.setenv("SMHIP_NARROW", "1")
+    aligned) stay bit-identical to the oracle; the `narrow` option forces them on an aligned input."""
     for w, h, b, D, win in ((61, 23, 1, 16, 9), (40, 17, 4, 7, 5), (33, 12, 1, 32, 4)):
         left, right = synth.noise_pair(w, h, b, seed=31 + D)
         kw = dict(disp_max=D - 1, match_fn=1, match_max=3, match_interval=1, aggr_window_size=win)
         odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-        m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
-        disp, best, _ = m.ComputeCorrespondence(left, right)
+        with gpu_ctx.options(narrow=1):
+            m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+            disp, best, _ = m.ComputeCorrespondence(left, right)
         assert m.used_fused
         assert np.array_equal(disp, odisp)
         util.assert_bit_equal(best, obest, "best cost")
@@ -234,23 +234,21 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     (90, 20, 4, 24, 9, 1, 1, dict(match_fn=1, match_interval=1)),              # a row shorter than one chunk
     (3000, 19, 4, 64, 9, 1, 1, dict(match_fn=1, match_interval=1)),            # chosen without the knob (48 KB row)
 ])
-def test_chunked_row_staging(gpu_ctx, oracle, monkeypatch, w, h, b, D, win, sign, step, kw):
+def test_chunked_row_staging(gpu_ctx, oracle, w, h, b, D, win, sign, step, kw):
     """Pass A with the row staged in chunks (smhip_fused_chunk.h: rows above 40 KB, e.g. 4-band 8K
-    frames; forced here through SMHIP_CHUNK) equals the oracle, and the whole-row kernel."""
+    frames; forced here through the `chunk` option) equals the oracle, and so do the whole-row kernel
+    and the library's own choice (the float-lane kernel where it applies)."""
     left, right = synth.noise_pair(w, h, b, seed=400 + w)
     fr, fm = (0, 1) if sign > 0 else (1, 0)
     seq = dict(disp_max=(D - 1) * step, disp_step=float(step), frame_ref=fr, frame_match=fm, aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **seq, **kw)
-    for force in ("1", "0", None):
-        if force is None:
-            monkeypatch.delenv("SMHIP_CHUNK", raising=False)
-        else:
-            monkeypatch.setenv("SMHIP_CHUNK", force)
-        m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
-        disp, best, _ = m.ComputeCorrespondence(left, right)
+    for force in (1, 0, -1):
+        with gpu_ctx.options(chunk=force):
+            m = matcher.StereoMatcher(ctx=gpu_ctx, **seq, **kw)
+            disp, best, _ = m.ComputeCorrespondence(left, right)
         assert m.used_fused
         assert np.array_equal(disp, odisp), force
-        util.assert_bit_equal(best, obest, "best cost (SMHIP_CHUNK=%s)" % force)
+        util.assert_bit_equal(best, obest, "best cost (chunk=%s)" % force)
 
 
 @pytest.mark.parametrize("d_first", [0, 1024, 1664, 1792])
@@ -273,18 +271,19 @@ def test_bench_geometry_of_eight_ranks(gpu_ctx, oracle, d_first):
 
 
 @pytest.mark.parametrize("w,h,D,win", [(96, 40, 16, 9), (1, 9, 4, 1), (2, 11, 8, 1), (130, 20, 64, 5), (300, 12, 256, 9)])
-def test_bt_interval_in_kernel_and_as_prepass(gpu_ctx, oracle, monkeypatch, w, h, D, win):
+def test_bt_interval_in_kernel_and_as_prepass(gpu_ctx, oracle, w, h, D, win):
     """One-band frames: pass A forms the matching row's Birchfield-Tomasi interval while staging the row
-    (first and last pixel replicate, StcRawCosts.cpp:107-128); SMHIP_BT_PREPASS=1 keeps the separate
-    pre-pass kernel that every other shape uses.  Both equal the oracle."""
+    (first and last pixel replicate, StcRawCosts.cpp:107-128); the `bt_prepass` option keeps the separate
+    pre-pass kernel that every other shape uses.  Both equal the oracle, with the float-lane and with
+    the integer kernels."""
     left, right = synth.noise_pair(w, h, 1, seed=w + D)
     kw = dict(disp_max=D - 1, aggr_window_size=win, match_fn=1, match_interval=1, match_max=1000)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    for prepass in (False, True):
-        if prepass:
-            monkeypatch.setenv("SMHIP_BT_PREPASS", "1")
-        m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
-        disp, best, _ = m.ComputeCorrespondence(left, right)
-        assert m.used_fused
-        util.assert_bit_equal(disp, odisp, "disparity prepass=%s" % prepass)
-        util.assert_bit_equal(best, obest, "best cost prepass=%s" % prepass)
+    for prepass in (0, 1):
+        for float_a in (1, 0):
+            with gpu_ctx.options(bt_prepass=prepass, float_a=float_a):
+                m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+                disp, best, _ = m.ComputeCorrespondence(left, right)
+            assert m.used_fused
+            util.assert_bit_equal(disp, odisp, "disparity prepass=%s float_a=%s" % (prepass, float_a))
+            util.assert_bit_equal(best, obest, "best cost prepass=%s float_a=%s" % (prepass, float_a))

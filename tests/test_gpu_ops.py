@@ -316,13 +316,14 @@ def test_subpixel_fit_collapse_refine(gpu_ctx, oracle, h, w, d):
                                        (40, 130, 7, 1)])
 @pytest.mark.parametrize("n_iter", [1, 2, 3, 4, 5, 7, 10])
 @pytest.mark.parametrize("maxk", ["", "4", "3"])
-def test_multi_iteration_passes(gpu_ctx, oracle, monkeypatch, h, w, d, pad, n_iter, maxk):
+def test_multi_iteration_passes(gpu_ctx, oracle, h, w, d, pad, n_iter, maxk, request):
     """smhip_diffusion_run / smhip_convolve_14641_run: up to four iterations per pass (temporal
     blocking across tiles of 64 pixels and row segments) == n_iter single iterations of the
     oracle, bit for bit; unaligned shapes take the one-iteration-per-pass route.  The depth per pass
-    follows the shape (small volumes: 1 or 2); SMHIP_MAXK forces the deeper kernels onto these shapes."""
+    follows the shape (small volumes: 1 or 2); the `maxk` option forces the deeper kernels onto these shapes."""
     if maxk:
-        monkeypatch.setenv("SMHIP_MAXK", maxk)
+        gpu_ctx.set_option("maxk", int(maxk))
+        request.addfinalizer(lambda: gpu_ctx.set_option("maxk", -1))
     c = util.rand_dsi(h, w, d, 80 + n_iter, "float")
     c0 = util.rand_dsi(h, w, d, 81, "float")
     re = w * d + pad
@@ -348,10 +349,11 @@ def test_multi_iteration_passes(gpu_ctx, oracle, monkeypatch, h, w, d, pad, n_it
     util.assert_bit_equal(result(bufs, in_b), want, "binomial x%d" % n_iter)
 
 
-def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, monkeypatch):
+def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, request):
     """Large volumes use 128-row segments in the LDS-tiled kernels; force that length on a small
-    volume (SMHIP_TSEG) so the segment logic of the production configuration is covered."""
-    monkeypatch.setenv("SMHIP_TSEG", "128")
+    volume (the `tseg` option) so the segment logic of the production configuration is covered."""
+    gpu_ctx.set_option("tseg", 128)
+    request.addfinalizer(lambda: gpu_ctx.set_option("tseg", -1))
     h, w, d = 300, 40, 8
     c = util.rand_dsi(h, w, d, 90, "float")
     src, dst = up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4)

@@ -19,7 +19,7 @@ def rccl_group():
     import torch
     import torch.distributed as dist
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    store = dist.TCPStore("127.0.0.1", 29653, 1, True)
+    store = dist.TCPStore("127.0.0.1", util.free_port(), 1, True)
     dist.init_process_group("nccl", store=store, rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield dist
     dist.destroy_process_group()

@@ -85,3 +85,11 @@ def crc32(a):
     import zlib
     import numpy as np
     return "%08x" % (zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF)
+
+
+def free_port():
+    """A TCP port nobody listens on right now (two sessions may share a box: no fixed rendezvous ports)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
