@@ -97,6 +97,38 @@ def test_disparity_slabs_merge_to_full_result(gpu_ctx, oracle, D, slabs):
     util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), obest, "merged best cost")
 
 
+@pytest.mark.parametrize("pair,kw", [
+    ("scene", dict(match_fn=1, match_interval=1, match_max=1000)),     # BASELINE config 3 as bench.py runs it
+    ("noise", dict(match_fn=1, match_interval=1, match_max=1000)),     # the no-structure pair
+    ("scene", dict(match_fn=1, match_interval=0, match_max=2)),        # the tie-stress run
+    ("noise", dict(match_fn=1, match_interval=0, match_max=2)),
+])
+def test_config3_full_size_vs_oracle(gpu_ctx, oracle, pair, kw):
+    """BASELINE config 3 at FULL size (1920x1080, D = 256, 9x9 box, WTA), device result against the
+    oracle's whole frame, bit for bit: disparity and best cost (OptWTA, StcOptimize.cpp:26-56, after the
+    running-sum box filter of BoxFilter.cpp:70-170).  The oracle runs its OpenMP build (bit-identical to
+    the serial one: test_oracle_pins.py)."""
+    from oracle import oracle as O
+    w, h, D = 1920, 1080, 256
+    if pair == "scene":
+        left, right, _ = synth.scene_pair(w, h, D)
+    else:
+        left, right = synth.noise_pair(w, h, 1, seed=0x5EED0002)
+    O.use_openmp(True)
+    try:
+        odisp, obest, odepth, _ = oracle_run(O, left, right, disp_max=D - 1, aggr_window_size=9, **kw)
+    finally:
+        O.use_openmp(False)
+    for float_a in (1, 0):                       # the float-lane pass A and the integer kernels
+        with gpu_ctx.options(float_a=float_a):
+            m = matcher.StereoMatcher(ctx=gpu_ctx, disp_max=D - 1, aggr_window_size=9, **kw)
+            disp, best, depth = m.ComputeCorrespondence(left, right)
+        assert m.used_fused
+        util.assert_bit_equal(disp, odisp, "disparity (float_a=%d)" % float_a)
+        util.assert_bit_equal(best, obest, "best cost (float_a=%d)" % float_a)
+        assert np.array_equal(depth, odepth)
+
+
 def test_full_size_properties(gpu_ctx):
     """BASELINE config 3 (1920x1080, D=256, BT-SAD, 9x9 box, WTA) at full size, through
     size-independent properties: slab-merge invariance, determinism, and agreement of the
