@@ -274,6 +274,18 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
                         size_t img_pitch, const smhip_match_params *p, int window,
                         int32_t *d_disp, float *d_best);
 
+/* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The slab of
+ * horizontal sums, the Birchfield-Tomasi images and the key image live in a static device array of
+ * SMHIP_NOALLOC_SCRATCH_BYTES that every device the library runs on holds until the process ends; the
+ * call itself makes no hipMalloc / hipFree.  Problems whose scratch does not fit are refused with
+ * SMHIP_ENOMEM (the slab alone takes width * roundup(height, 32) * Dp * 4 bytes, Dp = levels rounded up
+ * to 64 / 128 / a multiple of 256).  All calls on one device share that array: calls that overlap in
+ * time on one device (two contexts, two streams) race; results are those of smhip_fused_box_wta. */
+#define SMHIP_NOALLOC_SCRATCH_BYTES (64u << 20)
+int smhip_fused_box_wta_noalloc(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                                const smhip_match_params *p, int window, int32_t *d_disp, float *d_best);
+
 /* ---- kernel timing (replaces the Timer of CudaUtilities.h:47-68 / profilingTimer) ----
  * Between begin and end every smhip_fused_box_wta_keys() call brackets its two kernels with
  * HIP events on the context's stream (no synchronisation is added).  smhip_profile_end()

@@ -21,7 +21,7 @@ SYMBOLS = [
     "smhip_raw_costs", "smhip_box_filter", "smhip_min_filter", "smhip_min_filter_to",
     "smhip_convolve_14641", "smhip_convolve_14641_to",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
-    "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end", "smhip_profile_get",
+    "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end", "smhip_profile_get", "smhip_fused_box_wta_noalloc",
     "smhip_subpixel_fit", "smhip_collapse", "smhip_refine",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
@@ -129,6 +129,7 @@ def load():
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_keys_decode.argtypes = [vp, vp, ci, ci, vp, vp]
     L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
+    L.smhip_fused_box_wta_noalloc.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
     L.smhip_subpixel_fit.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, sz, cf]
     L.smhip_collapse.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, ci, sz, cf, vp, vp]
     L.smhip_refine.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, vp]
@@ -367,6 +368,11 @@ class Context:
     def fused_box_wta(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
         self._chk(self.L.smhip_fused_box_wta(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
                                              C.byref(p), window, _ptr(d_disp), _ptr(d_best)))
+
+    def fused_box_wta_noalloc(self, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best):
+        """smhip_fused_box_wta on the device's static scratch array: no device allocation in the call."""
+        self._chk(self.L.smhip_fused_box_wta_noalloc(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
+                                                     C.byref(p), window, _ptr(d_disp), _ptr(d_best)))
 
     def subpixel_fit(self, d_src, d_dst, d_min, d_cert, w, h, nb, row_elems, match_outside):
         self._chk(self.L.smhip_subpixel_fit(self.h, _ptr(d_src), _ptr(d_dst), _ptr(d_min), _ptr(d_cert),

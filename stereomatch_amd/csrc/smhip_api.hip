@@ -45,6 +45,13 @@ enum { WS_TMP = 0, WS_BT = 1, WS_KEYS = 2, WS_COUNT = 3 };
 
 }  // namespace
 
+// Scratch of the no-allocation entry point (smhip_fused_box_wta_noalloc): every device the library runs
+// on holds its own copy of this array until the process ends.  Host code never uses the array's name as
+// an address: smhip_init asks for the device's address once (hipGetSymbolAddress) and keeps it.
+static __device__ __align__(256) unsigned char smhip_static_scratch[SMHIP_NOALLOC_SCRATCH_BYTES];
+enum { SMHIP_MAX_DEVICES = 64 };
+static unsigned char *g_scratch_ptr[SMHIP_MAX_DEVICES];   // per device, filled by smhip_init
+
 struct smhip_ctx {
     int device;
     hipStream_t stream;
@@ -56,6 +63,13 @@ struct smhip_ctx {
     int bayes_n, bayes_band;             // levels they were computed for (0: none), half band width
     float bayes_sigma, bayes_eps;
     int opt[SMHIP_OPT_COUNT];            // smhip_set_option; -1 = the library's own policy
+    // no-allocation mode (inside smhip_fused_box_wta_noalloc): the workspace slots are carved out of this
+    // device's static scratch array instead of hipMalloc'ed
+    unsigned char *scratch;              // this device's address of smhip_static_scratch
+    bool arena_on;
+    size_t arena_used;
+    void *arena_ptr[WS_COUNT];
+    size_t arena_bytes[WS_COUNT];
 };
 
 namespace {
@@ -63,6 +77,19 @@ namespace {
 // grow-only device workspace slot
 int ws_get(smhip_ctx *ctx, int slot, size_t bytes, void **out)
 {
+    if (ctx->arena_on) {                 // carve from the static scratch: no hipMalloc, no hipFree
+        if (ctx->arena_bytes[slot] < bytes) {
+            size_t at = (ctx->arena_used + 255) & ~(size_t)255;
+            if (bytes > (size_t)SMHIP_NOALLOC_SCRATCH_BYTES || at > (size_t)SMHIP_NOALLOC_SCRATCH_BYTES - bytes)
+                return fail(SMHIP_ENOMEM, "the no-allocation entry point needs %zu more bytes of scratch, %zu of its "
+                            "%zu are taken: problem too large", bytes, at, (size_t)SMHIP_NOALLOC_SCRATCH_BYTES);
+            ctx->arena_ptr[slot] = ctx->scratch + at;
+            ctx->arena_bytes[slot] = bytes;
+            ctx->arena_used = at + bytes;
+        }
+        *out = ctx->arena_ptr[slot];
+        return SMHIP_OK;
+    }
     if (ctx->ws_bytes[slot] < bytes) {
         if (ctx->ws[slot]) {
             HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -242,6 +269,18 @@ int smhip_init(int device, smhip_ctx **out)
         return fail(SMHIP_ENOMEM, "out of host memory");
     ctx->device = device;
     ctx->stream = nullptr;
+    if (device < SMHIP_MAX_DEVICES) {    // this device's copy of the static scratch (device is current)
+        if (!g_scratch_ptr[device]) {
+            void *sp = nullptr;
+            hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(smhip_static_scratch));
+            if (e != hipSuccess || !sp) {
+                free(ctx);
+                return fail(SMHIP_EHIP, "hipGetSymbolAddress(smhip_static_scratch): %s", hipGetErrorString(e));
+            }
+            g_scratch_ptr[device] = (unsigned char *)sp;
+        }
+        ctx->scratch = g_scratch_ptr[device];
+    }
     for (int i = 0; i < SMHIP_OPT_COUNT; i++)
         ctx->opt[i] = -1;
     *out = ctx;
@@ -1585,6 +1624,27 @@ int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_m
     rc = smhip_fused_box_wta_keys(ctx, d_ref, d_mtc, img_pitch, p, window, 0, d_count, keys);
     if (rc) return rc;
     return smhip_keys_decode(ctx, keys, p->width, p->height, d_disp, d_best);
+}
+
+int smhip_fused_box_wta_noalloc(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                                const smhip_match_params *p, int window, int32_t *d_disp, float *d_best)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    if (!ctx->scratch)
+        return fail(SMHIP_EINVAL, "no static scratch on device %d (device index above %d)", ctx->device,
+                    SMHIP_MAX_DEVICES - 1);
+    // the slab, the interval images and the keys of this call live in the device's static scratch; the
+    // kernels and their order are those of smhip_fused_box_wta
+    ctx->arena_on = true;
+    ctx->arena_used = 0;
+    for (int i = 0; i < WS_COUNT; i++) {
+        ctx->arena_ptr[i] = nullptr;
+        ctx->arena_bytes[i] = 0;
+    }
+    rc = smhip_fused_box_wta(ctx, d_ref, d_mtc, img_pitch, p, window, d_disp, d_best);
+    ctx->arena_on = false;
+    return rc;
 }
 
 }  // extern "C"
