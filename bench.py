@@ -311,9 +311,35 @@ def oracle_frame(np, left, right, D, win):
 def extra_configs(np, capi, synth, ctx):
     """BASELINE configs 4 and 5 (per-GPU share), a few repetitions each, reported next to the
     headline line (not part of `value`): iterated aggregation on a resident 3840x2160x512 DSI and
-    the fused path on a 7680x4320 slab of 128 levels.  frac = SURVEY 8d algorithmic bytes / time /
-    8 TB/s.  Failures are reported, they do not stop the bench."""
+    the fused path on a 7680x4320 slab of 128 levels.  The iterated runs keep several iterations in LDS
+    per pass over the DSI (temporal blocking), so "8 bytes per voxel and iteration" is not what they move:
+    they are reported with the HBM bytes the PMC counters measured for their kernels at this very shape
+    (profiles/r02_stage_ops_summary.json, scripts/prof_ops_pmc.sh), the rate those bytes give over the time
+    measured here, and the share of SIMD cycles that had a vector instruction in flight.  Failures are
+    reported, they do not stop the bench."""
     res = {}
+    ops_prof = {}
+    ops_prof_path = os.path.join(ROOT, "profiles", "r02_stage_ops_summary.json")
+    if os.path.exists(ops_prof_path):
+        with open(ops_prof_path) as f:
+            ops_prof = json.load(f)
+
+    def run_counters(kernel_fmt, n_iter, dt, maxk=4):
+        """Launches of smhip_*_run for n_iter iterations (depths as multi_depth of smhip_api.hip splits
+        them) x the counters of each depth's kernel."""
+        left, passes, nbytes, valu_t, t = n_iter, (n_iter + maxk - 1) // maxk, 0, 0.0, 0.0
+        while left > 0:
+            k = (left + passes - 1) // passes
+            c = ops_prof.get(kernel_fmt % k)
+            if c is None:
+                return {"measured_bytes": None}
+            nbytes += c["measured_bytes"]
+            valu_t += c["valu_active_pct"] * c["avg_us"]
+            t += c["avg_us"]
+            left, passes = left - k, passes - 1
+        return {"measured_bytes": nbytes, "achieved_GBs": round(nbytes / dt / 1e9, 1),
+                "frac_of_8TBs": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 3), "valu_active_pct": round(valu_t / t, 1),
+                "counters_source": "profiles/r02_stage_ops_summary.json"}
 
     def timed(fn, reps):
         fn()
@@ -332,17 +358,18 @@ def extra_configs(np, capi, synth, ctx):
         d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
         a, b = ctx.alloc(N * 4), ctx.alloc(N * 4)
         ctx.raw_costs(d_ref, d_mtc, W, p, a, W * D)
-        for name, iters, fn in (
-                ("binomial_x4", 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
-                ("binomial_x8", 8, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),
-                ("diffusion_x10", 10, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 10)),
-                ("diffusion_x50", 50, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 50))):
+        bk, dk = "smk::binomial_multi_kernel<%d>", "smk::diffusion_multi_kernel<%d, false>"
+        for name, iters, kfmt, fn in (
+                ("binomial_x4", 4, bk, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
+                ("binomial_x8", 8, bk, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),
+                ("diffusion_x10", 10, dk, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 10)),
+                ("diffusion_x50", 50, dk, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 50))):
             dt = timed(fn, 2)
             res["config4_" + name] = {
                 "workload": "3840x2160, D=512, %d iterations on the resident DSI" % iters,
                 "ms": round(dt * 1e3, 3), "ms_per_iteration": round(dt * 1e3 / iters, 3),
-                "G_voxel_iterations_per_s": round(N * iters / dt / 1e9, 1),
-                "frac_of_8N_per_iteration": round(8.0 * N * iters / dt / 1e9 / HBM_PEAK_GBS, 3)}
+                "G_voxel_iterations_per_s": round(N * iters / dt / 1e9, 1)}
+            res["config4_" + name].update(run_counters(kfmt, iters, dt))
         a.free()
         b.free()
         # one GPU's share of config 4 under slab sharding (D = 512 over 8 GPUs): the staged pipeline on

@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Times the stage operators of the C-ABI on a resident DSI (BASELINE configs 2 and 4 shapes) and
 prints achieved GB/s against the algorithmic bytes of SURVEY 8d (8 bytes per voxel and filter
-application; WTA 4 bytes per voxel).  GPU box only:  python scripts/bench_ops.py [W H D]"""
+application; WTA 4 bytes per voxel).  The iterated "(run)" entries hold up to 4 iterations in LDS per pass
+over the DSI, so their bytes are 8 (membrane: 12) per voxel and PASS, ceil(n / 4) passes; their iteration
+rate is the "Gvox/s" column x n.  The HBM bytes the counters see for each kernel are in
+profiles/r02_stage_ops_summary.json (scripts/prof_ops_pmc.sh).  GPU box only:
+python scripts/bench_ops.py [W H D]"""
 import json
 import os
 import sys
@@ -51,12 +55,12 @@ def main():
     timed("diffusion_iter", 8.0 * N, lambda: ctx.diffusion_iter(cost, cost2, None, W, H, D, re, 0.15, 0.0))
     timed("membrane_iter", 12.0 * N, lambda: ctx.diffusion_iter(cost, cost2, cost, W, H, D, re, 0.15, 0.5))
     for n in (2, 4, 8):
-        timed("binomial x%d (run)" % n, 8.0 * N * n,
+        timed("binomial x%d (run)" % n, 8.0 * N * ((n + 3) // 4),
               lambda: ctx.convolve_14641_run(cost, cost2, W, H, D, re, n))
     for n in (4, 10):
-        timed("diffusion x%d (run)" % n, 8.0 * N * n,
+        timed("diffusion x%d (run)" % n, 8.0 * N * ((n + 3) // 4),
               lambda: ctx.diffusion_run(cost, cost2, None, W, H, D, re, 0.15, 0.0, n))
-    timed("membrane x4 (run)", 12.0 * N * 4,
+    timed("membrane x4 (run)", 12.0 * N,
           lambda: ctx.diffusion_run(cost, cost2, disp_src, W, H, D, re, 0.15, 0.5, 4))
     timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))

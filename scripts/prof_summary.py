@@ -18,7 +18,7 @@ if kt:
     res["kernel_trace"] = {k: {"calls": len(v), "avg_us": sum(v) / len(v) / 1e3,
                                "min_us": min(v) / 1e3, "pct": 100.0 * sum(v) / tot}
                            for k, v in dur.items()}
-for p in ("pmc1", "pmc2"):
+for p in sorted(d for d in os.listdir(out) if d.startswith("pmc") and os.path.isdir(os.path.join(out, d))):
     cc = glob.glob(os.path.join(out, p, "**", "*counter_collection.csv"), recursive=True)
     if not cc:
         continue
