@@ -74,7 +74,7 @@ enum smhip_option {
     SMHIP_OPT_TYSHIFT,        /* log2 of the band height of the fused path's private slab, 0..8 */
     SMHIP_OPT_CHUNK,          /* 1 / 0: pass A stages rows in chunks / whole (integer kernels) */
     SMHIP_OPT_BT_PREPASS,     /* 1: Birchfield-Tomasi intervals from the pre-pass kernel, always */
-    SMHIP_OPT_TSEG,           /* rows per workgroup of the LDS-tiled filters, 8..4096 */
+    SMHIP_OPT_TSEG,           /* rows per workgroup of the LDS-tiled filters, 8..4096 (min + WTA keys: 8..64) */
     SMHIP_OPT_MAXK,           /* iterations per pass of the multi-iteration filters, 1..4 */
     SMHIP_OPT_FLOAT_A,        /* 0: pass A by the integer kernels also where the float-lane kernel applies */
     SMHIP_OPT_KEYBUF,         /* key groups (of ~64 rows) pass B collects in LDS before it stores them; 0: none */

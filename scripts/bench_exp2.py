@@ -44,11 +44,21 @@ def main():
     def min_keys_only():
         ctx.min_pad_wta_keys(cost, re, p, 9, 0, D, keys)
 
+    def min_keys_seg64():
+        with ctx.options(tseg=64):
+            ctx.min_pad_wta_keys(cost, re, p, 9, 0, D, keys)
+
+    def min_keys_seg16():
+        with ctx.options(tseg=16):
+            ctx.min_pad_wta_keys(cost, re, p, 9, 0, D, keys)
+
     out = {}
     for name, fn, nbytes in (("staged (raw, box, min, pad, wta)", staged, 16.0 * N),
                              ("fused (box->DSI, min+pad+WTA keys)", fused, 16.0 * N),
                              ("  smhip_fused_box_dsi", box_dsi_only, 12.0 * N),
-                             ("  smhip_min_pad_wta_keys", min_keys_only, 4.0 * N)):
+                             ("  smhip_min_pad_wta_keys", min_keys_only, 4.0 * N),
+                             ("  (same, 64-row segments)", min_keys_seg64, 4.0 * N),
+                             ("  (same, 16-row segments)", min_keys_seg16, 4.0 * N)):
         fn()
         ctx.sync()
         t0 = time.perf_counter()

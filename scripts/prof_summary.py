@@ -34,5 +34,5 @@ with open(os.path.join(out, "summary.json"), "w") as f:
 for k, v in sorted(res.get("kernel_trace", {}).items(), key=lambda kv: -kv[1]["pct"]):
     print("%-70s calls %3d avg %9.1f us min %9.1f us  %5.1f%%" % (k[:70], v["calls"], v["avg_us"], v["min_us"], v["pct"]))
 for k, d in res.get("pmc", {}).items():
-    if "fused" in k:
+    if "fused" in k or len(res["pmc"]) <= 12:
         print(k[:60], {c: round(x, 1) for c, x in sorted(d.items())})

@@ -25,10 +25,26 @@ int next_int(FILE *f, const char *filename)
     }
     if (c < '0' || c > '9')
         throw CError("ReadImage(%s): malformed header", filename);
-    int v = 0;
-    while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = getc(f); }
+    long long v = 0;
+    while (c >= '0' && c <= '9') {
+        v = v * 10 + (c - '0');
+        if (v > 0x7fffffffLL)
+            throw CError("ReadImage(%s): header value out of range", filename);
+        c = getc(f);
+    }
     ungetc(c, f);
-    return v;
+    return (int)v;
+}
+
+// width x height x bytes per pixel must be positive and small enough for one allocation: a corrupt
+// header must not turn into a huge or negative size
+void check_dims(int w, int h, int b, size_t elem, const char *filename)
+{
+    const unsigned long long cap = 1ULL << 34;     // 16 GiB
+    if (w <= 0 || h <= 0 || b <= 0 ||
+        (unsigned long long)w * (unsigned long long)b * elem > cap ||
+        (unsigned long long)w * (unsigned long long)b * elem * (unsigned long long)h > cap)
+        throw CError("ReadImage(%s): invalid image size %d x %d x %d", filename, w, h, b);
 }
 
 bool ends_with(const char *s, const char *ext)
@@ -50,7 +66,10 @@ void ReadImage(CByteImage &img, const char *filename)
     if (getc(in.f) != 'P' || getc(in.f) != (gray ? '5' : '6'))
         throw CError("ReadImage(%s): wrong magic code", filename);
     int w = next_int(in.f, filename), h = next_int(in.f, filename);
-    (void)next_int(in.f, filename);
+    int maxval = next_int(in.f, filename);
+    check_dims(w, h, gray ? 1 : 4, 1, filename);
+    if (maxval < 1 || maxval > 255)                  // one byte per sample is all the path handles
+        throw CError("ReadImage(%s): maxval %d not supported (1..255)", filename, maxval);
     int c = getc(in.f);
     if (c == '\r') c = getc(in.f);
     if (c != '\n')
@@ -114,6 +133,7 @@ void ReadImage(CFloatImage &img, const char *filename)
     if (c == '\r') c = getc(in.f);
     if (c != '\n')
         throw CError("ReadImage(%s): newline expected after the header", filename);
+    check_dims(w, h, b, sizeof(float), filename);
     img.ReAllocate(CShape(w, h, b));
     size_t n = (size_t)w * b * sizeof(float);
     for (int y = 0; y < h; y++)

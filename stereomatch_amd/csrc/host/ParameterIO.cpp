@@ -1,38 +1,109 @@
-// ParameterIO.cpp -- see ParameterIO.h (behaviour of the reference's ParameterIO.cpp:21-119).
+// ParameterIO.cpp -- see ParameterIO.h.
 #include "ParameterIO.h"
 #include "Error.h"
-#include <cstring>
+#include <cstdlib>
 
-void CParameterIO::PushParamPair(const char *name, const char *format, void *value_loc)
+void CParameterIO::Add(const char *name, Kind kind, void *loc)
 {
-    m_entries.push_back(Entry{name, format, value_loc});
+    m_index.emplace(name, m_params.size());
+    m_params.push_back(Param{name, kind, loc});
 }
 
-void CParameterIO::ReadParamPair(const char *name, const char *value, bool warn_bad_name)
+void CParameterIO::PushParamPair(const char *name, std::string *text) { Add(name, Kind::Text, text); }
+void CParameterIO::PushParamPair(const char *name, float *real) { Add(name, Kind::Real, real); }
+void CParameterIO::PushParamPair(const char *name, int *integer, bool hex)
 {
-    for (Entry &e : m_entries)
-        if (e.name == name) {
-            sscanf(value, e.format.c_str(), e.loc);
-            return;
+    Add(name, hex ? Kind::Hex : Kind::Integer, integer);
+}
+
+// A value that does not parse leaves the variable as it was (what scanf does with a failed conversion).
+void CParameterIO::Param::Parse(const std::string &value) const
+{
+    const char *s = value.c_str();
+    char *end = nullptr;
+    switch (kind) {
+    case Kind::Text:
+        *static_cast<std::string *>(loc) = value;
+        break;
+    case Kind::Real: {
+        float v = strtof(s, &end);
+        if (end != s)
+            *static_cast<float *>(loc) = v;
+        break;
+    }
+    case Kind::Integer: {
+        long v = strtol(s, &end, 10);
+        if (end != s)
+            *static_cast<int *>(loc) = (int)v;
+        break;
+    }
+    case Kind::Hex:                                    // written as 0x%08x, read back the same way
+        if (value.size() > 2 && s[0] == '0' && s[1] == 'x') {
+            unsigned long v = strtoul(value.substr(2, 8).c_str(), &end, 16);
+            *static_cast<int *>(loc) = (int)(unsigned)v;
         }
-    if (strcmp(name, "script") == 0 || strcmp(name, "cd") == 0)
+        break;
+    }
+}
+
+bool CParameterIO::Param::Print(std::string &out) const
+{
+    char buf[64];
+    switch (kind) {
+    case Kind::Text:
+        out = *static_cast<const std::string *>(loc);
+        return !out.empty();
+    case Kind::Real:
+        snprintf(buf, sizeof(buf), "%f", *static_cast<const float *>(loc));
+        break;
+    case Kind::Integer:
+        snprintf(buf, sizeof(buf), "%d", *static_cast<const int *>(loc));
+        break;
+    case Kind::Hex:
+        snprintf(buf, sizeof(buf), "0x%08x", (unsigned)*static_cast<const int *>(loc));
+        break;
+    }
+    out = buf;
+    return true;
+}
+
+void CParameterIO::Assign(const std::string &name, const std::string &value, bool warn_bad_name)
+{
+    auto it = m_index.find(name);
+    if (it != m_index.end()) {
+        m_params[it->second].Parse(value);
         return;
-    if (warn_bad_name)
-        fprintf(stderr, "Warning: CParameterIO::ReadParamPair: unknown parameter %s\n", name);
+    }
+    // `script` and `cd` are commands of the interpreter that travel through the same pair lists
+    if (warn_bad_name && name != "script" && name != "cd")
+        fprintf(stderr, "Warning: parameter '%s' is not known and was ignored\n", name.c_str());
 }
 
 void CParameterIO::ReadFromStream(FILE *stream)
 {
-    char name[1024], value[1024];
-    while (fscanf(stream, "%1023s %1023s", name, value) == 2)
-        ReadParamPair(name, value);
+    // the whole stream is a white-space separated list name value name value ...
+    std::vector<std::string> words;
+    std::string word;
+    for (int c; (c = getc(stream)) != EOF;) {
+        bool space = c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v';
+        if (!space)
+            word.push_back((char)c);
+        else if (!word.empty()) {
+            words.push_back(word);
+            word.clear();
+        }
+    }
+    if (!word.empty())
+        words.push_back(word);
+    for (size_t i = 0; i + 1 < words.size(); i += 2)
+        Assign(words[i], words[i + 1], true);
 }
 
 void CParameterIO::ReadFromFile(const char *filename)
 {
     FILE *stream = fopen(filename, "r");
     if (!stream)
-        throw CError("CParameterIO::ReadFromFile: could not open %s", filename);
+        throw CError("parameter file: could not open %s for reading", filename);
     ReadFromStream(stream);
     fclose(stream);
 }
@@ -40,44 +111,29 @@ void CParameterIO::ReadFromFile(const char *filename)
 void CParameterIO::ReadFromCommandLine(int argc, const char *argv[], bool warn_bad_name)
 {
     for (int i = 0; i + 1 < argc; i += 2)
-        ReadParamPair(argv[i], argv[i + 1], warn_bad_name);
+        Assign(argv[i], argv[i + 1], warn_bad_name);
 }
 
 void CParameterIO::WriteToStream(FILE *stream, bool single_line)
 {
-    for (const Entry &e : m_entries) {
-        char kind = e.format.back();
-        if (kind == 's') {
-            const char *s = static_cast<const char *>(e.loc);
-            if (!s[0])
-                continue;
-            fprintf(stream, "%s ", e.name.c_str());
-            fprintf(stream, e.format.c_str(), s);
-        } else if (kind == 'f') {
-            fprintf(stream, "%s ", e.name.c_str());
-            fprintf(stream, e.format.c_str(), *static_cast<const float *>(e.loc));
-        } else if (kind == 'd' || kind == 'x') {
-            fprintf(stream, "%s ", e.name.c_str());
-            fprintf(stream, e.format.c_str(), *static_cast<const int *>(e.loc));
-        } else {
-            throw CError("CParamaterIO: illegal format '%s'\n", e.format.c_str());
-        }
-        fputs(single_line ? " " : "\n", stream);
-    }
+    const char *separator = single_line ? " " : "\n";
+    std::string text;
+    for (const Param &p : m_params)
+        if (p.Print(text))
+            fprintf(stream, "%s %s%s", p.name.c_str(), text.c_str(), separator);
     if (single_line)
-        fputs("\n", stream);
+        fputc('\n', stream);
 }
 
 void CParameterIO::WriteToFile(const char *filename)
 {
-    bool append = filename[0] == '+';
-    if (append)
-        filename++;
-    FILE *stream = fopen(filename, append ? "a" : "w");
+    const bool append = filename[0] == '+';
+    const char *path = filename + (append ? 1 : 0);
+    FILE *stream = fopen(path, append ? "a" : "w");
     if (!stream)
-        throw CError("CParameterIO::WriteToFile: could not open %s", filename);
+        throw CError("parameter file: could not open %s for writing", path);
     WriteToStream(stream);
     if (append)
-        fputs("\n", stream);
+        fputc('\n', stream);                           // blank line between appended records
     fclose(stream);
 }

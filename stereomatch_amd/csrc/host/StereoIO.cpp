@@ -6,14 +6,10 @@
 #include <string>
 #include <unistd.h>
 
-CStereoFrameDescriptor::CStereoFrameDescriptor() { memset(this, 0, sizeof(*this)); }
-
 void CStereoFrameDescriptor::PIOInitialize(CParameterIO &o)
 {
     o.PPPS(input_file); o.PPPS(depth_file); o.PPPS(truth_file); o.PPPS(resampled_file);
 }
-
-CStereoIOParameters::CStereoIOParameters() { memset(this, 0, sizeof(*this)); }
 
 void CStereoIOParameters::PIOInitialize(CParameterIO &o)
 {
@@ -47,10 +43,11 @@ std::vector<std::string> Tokenize(const char *line)
     return out;
 }
 
-void ReadIfThere(CByteImage &img, const char *filename, bool ok_if_not_there, int verbose)
+void ReadIfThere(CByteImage &img, const std::string &path, bool ok_if_not_there, int verbose)
 {
-    if (!filename[0])
+    if (path.empty())
         return;
+    const char *filename = path.c_str();
     if (verbose >= eVerboseFileIO)
         fprintf(stderr, "reading image %s\n", filename);
     try {
@@ -67,68 +64,115 @@ void ReadIfThere(CByteImage &img, const char *filename, bool ok_if_not_there, in
 
 }  // namespace
 
+// One line of the grammar (StereoIO.cpp:168-279 defines what a line means; StereoIO.h here lists it).
+// A line is handled in phases, each a method of its own:
+//   BeginLine      the use-once file names are cleared and the line's pairs are read a first time
+//   a command      `script`, `cd`, `reset`, `exit` (table below); only `reset` lets the line go on
+//   LoadLineInputs input_params file, then the line's pairs again (the line overrides the file), frames
+//   PlanOutputs    where the depth map and the result file go; false = the line only set parameters
+//   RunMatcher, WriteLineOutputs
 int CStereoIO::InterpretCommandLine(int argc, const char *argv[])
 {
-    const char *command = argc > 1 ? argv[1] : nullptr;
-    const char *argument = argc > 2 ? argv[2] : "";
+    if (argc < 2 || !argv[1][0])
+        throw CError("No command is given on command line.");
+    BeginLine(argc, argv);
+
+    struct Command { const char *word; LineFlow (CStereoIO::*run)(const std::string &argument); };
+    static const Command commands[] = {
+        {"script", &CStereoIO::CommandScript}, {"cd", &CStereoIO::CommandChangeDir},
+        {"reset", &CStereoIO::CommandReset}, {"exit", &CStereoIO::CommandExit}};
+    const std::string word = argv[1], argument = argc > 2 ? argv[2] : "";
+    for (const Command &c : commands)
+        if (word == c.word) {
+            LineFlow flow = (this->*c.run)(argument);
+            if (flow != LineFlow::GoOn)
+                return flow == LineFlow::StopScript ? 1 : 0;
+        }
+
+    LoadLineInputs(argc, argv);
+    if (!PlanOutputs())
+        return 0;
+    RunMatcher();
+    WriteLineOutputs();
+    return 0;
+}
+
+void CStereoIO::BeginLine(int argc, const char *argv[])
+{
     static_cast<CStereoIOParameters &>(*this) = CStereoIOParameters();
     m_pio.ReadFromCommandLine(argc - 1, argv + 1);
-    if (!command || !command[0])
-        throw CError("No command is given on command line.");
+}
 
-    if (strcmp("script", command) == 0) {
-        InterpretScriptFile(argument);
-        return 0;
-    }
-    if (strcmp("cd", command) == 0) {
-        if (chdir(argument))
-            throw CError("Could not cd to %s", argument);
-        return 0;
-    }
-    if (strcmp("reset", command) == 0)
-        ReInitializeAlgParams();
-    if (strcmp("exit", command) == 0)
-        return 1;
+CStereoIO::LineFlow CStereoIO::CommandScript(const std::string &file)
+{
+    InterpretScriptFile(file.c_str());
+    return LineFlow::LineDone;
+}
 
+CStereoIO::LineFlow CStereoIO::CommandChangeDir(const std::string &dir)
+{
+    if (chdir(dir.c_str()) != 0)
+        throw CError("Could not cd to %s", dir.c_str());
+    return LineFlow::LineDone;
+}
+
+CStereoIO::LineFlow CStereoIO::CommandReset(const std::string &)
+{
+    ReInitializeAlgParams();
+    return LineFlow::GoOn;
+}
+
+CStereoIO::LineFlow CStereoIO::CommandExit(const std::string &) { return LineFlow::StopScript; }
+
+void CStereoIO::LoadLineInputs(int argc, const char *argv[])
+{
     ReadParameters();
-    m_pio.ReadFromCommandLine(argc - 1, argv + 1, false);   // the line overrides the file
+    m_pio.ReadFromCommandLine(argc - 1, argv + 1, false);
     ResetOutputParams();
     ReadData();
-    if (frame_ref >= 0 && frame_ref < (int)m_fd.size() && depth_map[0])
-        strcpy(m_fd[frame_ref].depth_file, depth_map);
-    if (!depth_map[0] && !output_params[0])
-        return 0;
-    if (frame_ref >= (int)m_fd.size() || frame_match >= (int)m_fd.size())
+}
+
+bool CStereoIO::PlanOutputs()
+{
+    const int n_frames = (int)m_fd.size();
+    if (!depth_map.empty() && frame_ref >= 0 && frame_ref < n_frames)
+        m_fd[frame_ref].depth_file = depth_map;
+    if (depth_map.empty() && output_params.empty())
+        return false;
+    if (frame_ref >= n_frames || frame_match >= n_frames)
         throw CError("Data has not yet been read in");
-    if (evaluate_only)                                        // StereoIO.cpp:254-257: the map to evaluate
+    if (evaluate_only)                                  // the map to evaluate comes from the file
         ReadIfThere(m_frame[frame_ref].depth_image, depth_map, false, verbose);
-    if (!output_params[0]) {                                  // results/x.pgm -> results/x.txt
-        strcpy(output_params, depth_map);
-        strcpy(&output_params[strlen(output_params) - 3], "txt");
+    if (output_params.empty()) {                        // results/x.pgm -> results/x.txt
+        size_t stem = depth_map.size() >= 3 ? depth_map.size() - 3 : 0;
+        output_params = depth_map.substr(0, stem) + "txt";
     }
-    RunMatcher();
+    return true;
+}
+
+void CStereoIO::WriteLineOutputs()
+{
     WriteData();
     WriteParameters();
     if (verbose >= eVerboseSummary)
-        fprintf(stderr, "  writing %s\n", output_params[0] ? output_params : depth_map);
-    return 0;
+        fprintf(stderr, "  writing %s\n", output_params.c_str());
 }
 
 void CStereoIO::RunMatcher()
 {
-    if (depth_map[0]) {
+    if (!depth_map.empty()) {
         // cost_map ("cost map (DSI), for debugging", StereoIO.h:85 -- declared but unused in the
         // reference): here it names the file the aggregated DSI is written to, one PGM per level
         // ("..._%03d.pgm") or the whole volume as one .pmf; the DSI has to exist for that
         bool fused = allow_fused;
-        if (cost_map[0])
+        if (!cost_map.empty())
             allow_fused = false;
         ComputeCorrespondence();
         allow_fused = fused;
-        if (cost_map[0] && !evaluate_only)
-            WriteCosts(cost_map);
+        if (!cost_map.empty() && !evaluate_only)
+            WriteCosts(cost_map.c_str());
     }
-    if (output_params[0])
+    if (!output_params.empty())
         Evaluate();
 }
 
@@ -161,23 +205,23 @@ void CStereoIO::InterpretScriptFile(const char *script_file)
 
 void CStereoIO::ReadParameters()
 {
-    if (input_params[0])
-        m_pio.ReadFromFile(input_params);
+    if (!input_params.empty())
+        m_pio.ReadFromFile(input_params.c_str());
 }
 
 void CStereoIO::WriteParameters()
 {
-    if (output_params[0])
-        m_pio.WriteToFile(output_params);
+    if (!output_params.empty())
+        m_pio.WriteToFile(output_params.c_str());
 }
 
 void CStereoIO::ReadData()
 {
-    if (!input_data[0])
+    if (input_data.empty())
         return;
-    FILE *stream = fopen(input_data, "r");
+    FILE *stream = fopen(input_data.c_str(), "r");
     if (!stream)
-        throw CError("ReadData: could not open %s", input_data);
+        throw CError("ReadData: could not open %s", input_data.c_str());
     char line[4096];
     m_fd.clear();
     m_frame.clear();
@@ -190,8 +234,8 @@ void CStereoIO::ReadData()
             for (const std::string &t : tok) argv.push_back(t.c_str());
             m_fd0 = CStereoFrameDescriptor();
             m_dio.ReadFromCommandLine((int)argv.size(), argv.data());
-            if ((int)m_fd.size() == frame_ref && depth_map[0])
-                strcpy(m_fd0.depth_file, depth_map);
+            if ((int)m_fd.size() == frame_ref && !depth_map.empty())
+                m_fd0.depth_file = depth_map;
             m_fd.push_back(m_fd0);
             CStereoFrame fr;
             ReadIfThere(fr.input_image, m_fd0.input_file, false, verbose);
@@ -209,23 +253,23 @@ void CStereoIO::ReadData()
 void CStereoIO::WriteData()
 {
     FILE *stream = nullptr;
-    if (output_data[0]) {
-        stream = fopen(output_data, "w");
+    if (!output_data.empty()) {
+        stream = fopen(output_data.c_str(), "w");
         if (!stream)
-            throw CError("WriteData: could not open %s", output_data);
+            throw CError("WriteData: could not open %s", output_data.c_str());
     }
     for (size_t i = 0; i < m_fd.size(); i++) {
         m_fd0 = m_fd[i];
         CStereoFrame &fr = m_frame[i];
-        if (!evaluate_only && m_fd0.depth_file[0] && fr.depth_image.Shape().height > 0) {
+        if (!evaluate_only && !m_fd0.depth_file.empty() && fr.depth_image.Shape().height > 0) {
             if (verbose >= eVerboseFileIO)
-                fprintf(stderr, "writing image %s\n", m_fd0.depth_file);
-            WriteImage(fr.depth_image, m_fd0.depth_file);
+                fprintf(stderr, "writing image %s\n", m_fd0.depth_file.c_str());
+            WriteImage(fr.depth_image, m_fd0.depth_file.c_str());
         }
-        if (m_fd0.resampled_file[0] && fr.resampled_image.Shape().height > 0) {   // StereoIO.cpp:95-112
+        if (!m_fd0.resampled_file.empty() && fr.resampled_image.Shape().height > 0) {   // StereoIO.cpp:95-112
             if (verbose >= eVerboseFileIO)
-                fprintf(stderr, "writing image %s\n", m_fd0.resampled_file);
-            WriteImage(fr.resampled_image, m_fd0.resampled_file);
+                fprintf(stderr, "writing image %s\n", m_fd0.resampled_file.c_str());
+            WriteImage(fr.resampled_image, m_fd0.resampled_file.c_str());
         }
         if (stream)
             m_dio.WriteToStream(stream, true);

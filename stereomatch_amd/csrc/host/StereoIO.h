@@ -5,18 +5,16 @@
 // runs the matcher and writes <out>.pgm and <out>.txt.
 #pragma once
 #include "StereoMatcher.h"
+#include <string>
 
 struct CStereoFrameDescriptor {
-    char input_file[1024], depth_file[1024], truth_file[1024], resampled_file[1024];
-    CStereoFrameDescriptor();
+    std::string input_file, depth_file, truth_file, resampled_file;
     void PIOInitialize(CParameterIO &o);
 };
 
 struct CStereoIOParameters {
     // "use once" parameters, cleared on every command line (StereoIO.cpp:175)
-    char input_params[1024], output_params[1024], input_data[1024], output_data[1024];
-    char depth_map[1024], cost_map[1024];
-    CStereoIOParameters();
+    std::string input_params, output_params, input_data, output_data, depth_map, cost_map;
     void PIOInitialize(CParameterIO &o);
 };
 
@@ -26,6 +24,16 @@ public:
     int InterpretCommandLine(int argc, const char *argv[]);   // returns 1 on `exit`
 
 protected:
+    // what a command of the interpreter does to the rest of its line
+    enum class LineFlow { GoOn, LineDone, StopScript };
+    void BeginLine(int argc, const char *argv[]);
+    LineFlow CommandScript(const std::string &file);
+    LineFlow CommandChangeDir(const std::string &dir);
+    LineFlow CommandReset(const std::string &);
+    LineFlow CommandExit(const std::string &);
+    void LoadLineInputs(int argc, const char *argv[]);
+    bool PlanOutputs();
+    void WriteLineOutputs();
     void InterpretScriptFile(const char *script_file);
     void ReadParameters();
     void WriteParameters();

@@ -6,6 +6,7 @@
 #include "smhip_fused_chunk.h"
 #include "smhip_fused_f_launch.h"
 #include "smhip_stencil.h"
+#include "smhip_minwta.h"
 #include "smhip_subpix.h"
 #include "smhip_stage.h"
 #include "smhip_refine.h"
@@ -1480,30 +1481,36 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     int w = p->width, h = p->height;
     rc = check_dsi(d_cost, w, h, d_count, row_elems);
     if (rc) return rc;
-    const int tseg = tile_seglen(ctx, w, h, d_count);
-    dim3 tgrid((w + 31) / 32, (d_count + 31) / 32, (h + tseg - 1) / tseg);
     if (walk_vec(d_count, row_elems, d_cost, nullptr, nullptr) != 4 || min_window % 2 != 1 || min_window < 3 ||
-        min_window > 11 || tgrid.y > 65535 || tgrid.z > 65535)
+        min_window > 11)
         return fail(SMHIP_EINVAL, "min filter + WTA keys needs an odd window 3..11, D %% 4 == 0 and 16-byte aligned rows");
-    size_t n_pix = (size_t)w * h;
-    smk::fill_keys_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
-        (long long *)d_keys, n_pix, 0x7FFFFFFFFFFFFFFFll);
     smk::PadWtaArgs pw;
     pw.dstep = -p->frame_diff_sign * p->disp_num;
     pw.disp0 = -p->frame_diff_sign * p->disp_min + d_first * pw.dstep;
     pw.d_first = d_first;
     pw.outside = smhip_match_outside(p);
     pw.keys = (long long *)d_keys;
-#define LAUNCH_TW(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32, true><<<tgrid, 256, 0, ctx->stream>>>( \
-        d_cost, nullptr, w, d_count, h, row_elems, tseg, pw)
+    // Rows per workgroup: 64 at most (the keys of a segment live in LDS); shorter segments where the frame
+    // would otherwise give too few workgroups (1920x1080: 32 rows, 0.66 ms at 256 levels against 0.76 ms
+    // with 64 and 0.71 ms with 16 -- each segment re-reads WIN - 1 rows).  SMHIP_OPT_TSEG forces a length.
+    const int txo = 64 - (min_window - 1);
+    int seg = smk::MW_SEG;
+    while (seg > 16 && (long)((w + txo - 1) / txo) * ((h + seg - 1) / seg) < 1024)
+        seg >>= 1;
+    if (ctx->opt[SMHIP_OPT_TSEG] >= 8 && ctx->opt[SMHIP_OPT_TSEG] <= smk::MW_SEG)
+        seg = ctx->opt[SMHIP_OPT_TSEG];
+    dim3 grid((w + txo - 1) / txo, (h + seg - 1) / seg);
+    if (grid.y > 65535)
+        return fail(SMHIP_EINVAL, "min filter + WTA keys: more than %d rows", 65535 * seg);
+#define LAUNCH_MW(WIN) smk::min_wta_tile_kernel<WIN><<<grid, 512, 0, ctx->stream>>>(d_cost, w, d_count, h, row_elems, seg, pw)
     switch (min_window) {
-    case 3: LAUNCH_TW(3); break;
-    case 5: LAUNCH_TW(5); break;
-    case 7: LAUNCH_TW(7); break;
-    case 9: LAUNCH_TW(9); break;
-    default: LAUNCH_TW(11); break;
+    case 3: LAUNCH_MW(3); break;
+    case 5: LAUNCH_MW(5); break;
+    case 7: LAUNCH_MW(7); break;
+    case 9: LAUNCH_MW(9); break;
+    default: LAUNCH_MW(11); break;
     }
-#undef LAUNCH_TW
+#undef LAUNCH_MW
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }

@@ -113,16 +113,29 @@ __global__ __launch_bounds__(256) void binomial_walk_kernel(const float *__restr
 // ---- separable min filter -----------------------------------------------------------------
 // o[y][x] = min over rows y+pl+1..y+pr of (min over x+pl+1..x+pr), replicate border
 // (MinFilter.cpp:139-140, :49-52); min is exact in any order.  WIN is the (square) window.
+// One v_min_f32 per element.  `b < a ? b : a` compiles to v_cmp + s_nop + v_cndmask (three issue slots:
+// the select has to wait for VCC), and fminf() adds a canonicalising v_max per loaded operand; the
+// instruction itself is what is wanted.  It differs from the compare-and-select form only where the
+// reference's own two variants differ (MinFilter.cpp:29-82 against :85-120): a window holding both +0
+// and -0 yields -0 whatever the order (costs are sums of non-negative terms: no -0 arises on the path),
+// and a NaN loses against a number.
+__device__ __forceinline__ float fmin_hw(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int V>
 __device__ __forceinline__ typename fvec<V>::type vmin(typename fvec<V>::type a, typename fvec<V>::type b)
 {
     if constexpr (V == 1) {
-        return b < a ? b : a;
+        return fmin_hw(a, b);
     } else {
         typename fvec<V>::type r;
 #pragma unroll
         for (int i = 0; i < V; i++)
-            r[i] = b[i] < a[i] ? b[i] : a[i];
+            r[i] = fmin_hw(a[i], b[i]);
         return r;
     }
 }
@@ -180,6 +193,11 @@ __global__ __launch_bounds__(256) void minfilter_walk_kernel(const float *__rest
 template <int WIN_> struct MinOp {
     static constexpr int WIN = WIN_;
     static constexpr bool SYMMETRIC = true;     // v() does not depend on the order of the rows
+    // The vertical window minimum costs O(1) per row (van Herk / Gil-Werman): rows come in groups of WIN;
+    // the window of an output row is a suffix of the previous group plus a prefix of the current one, so
+    // one running prefix minimum, one suffix pass at the end of each group and one combining minimum per
+    // row replace the WIN - 1 minima over the ring: (3 WIN - 3) / WIN instead of WIN - 1 per row.
+    static constexpr bool VANHERK = true;
     typedef typename fvec<4>::type vec;
     static __device__ __forceinline__ vec h(const vec *w)
     {
@@ -194,34 +212,13 @@ template <int WIN_> struct MinOp {
 struct BinomOp {
     static constexpr int WIN = 5;
     static constexpr bool SYMMETRIC = false;
+    static constexpr bool VANHERK = false;
     typedef typename fvec<4>::type vec;
     static __device__ __forceinline__ vec h(const vec *w) { return vtap5<4>(w[0], w[1], w[2], w[3], w[4]); }
     static __device__ __forceinline__ vec v(const vec *r) { return vtap5<4>(r[0], r[1], r[2], r[3], r[4]); }
 };
 
-// WTA = true: the filtered value is not stored; PadCosts (StcRawCosts.cpp:437-457) is applied in
-// registers, the 8 lanes of a pixel min-reduce (ordered cost, level) and one lane merges the
-// result of this 32-level tile into the pixel's key with a 64-bit atomic min (keys start at
-// INT64_MAX; column-major like the fused path).  The filtered DSI is never written.
-// Lexicographic (s, d) minimum of each aligned group of 8 lanes, delivered to the group's first
-// lane (DPP row_shl 1, 2, 4; the levels of a group ascend with the lane, so on equal s the lower
-// lane keeps its own pair).
-__device__ __forceinline__ void seg8_min_to_first(int &s, int &d)
-{
-#define SMK_SEG8_STEP(CTRL)                                                              \
-    {                                                                                    \
-        int os = __builtin_amdgcn_update_dpp(0x7FFFFFFF, s, CTRL, 0xF, 0xF, false);      \
-        int od = __builtin_amdgcn_update_dpp(0x7FFFFFFF, d, CTRL, 0xF, 0xF, false);      \
-        bool take = os < s;                                                              \
-        s = take ? os : s;                                                               \
-        d = take ? od : d;                                                               \
-    }
-    SMK_SEG8_STEP(0x101)   // row_shl:1
-    SMK_SEG8_STEP(0x102)   // row_shl:2
-    SMK_SEG8_STEP(0x104)   // row_shl:4
-#undef SMK_SEG8_STEP
-}
-
+// arguments of the PadCosts + WTA stage fused behind a filter (smhip_minwta.h)
 struct PadWtaArgs {
     int disp0, dstep;        // disp(k) = disp0 + k*dstep for level k of this DSI
     int d_first;             // global index of level 0
@@ -229,11 +226,10 @@ struct PadWtaArgs {
     long long *keys;
 };
 
-template <class OP, int TX, bool WTA = false>
+template <class OP, int TX>
 __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restrict__ src,
                                                            float *__restrict__ dst, int W, int D, int H,
-                                                           size_t row_elems, int seglen,
-                                                           PadWtaArgs pw = PadWtaArgs())
+                                                           size_t row_elems, int seglen)
 {
     typedef typename fvec<4>::type vec;
     constexpr int WIN = OP::WIN, PR = WIN / 2, PL = PR - WIN;
@@ -264,19 +260,10 @@ __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restri
     };
     const bool live = (x0 + px < W) && (k0 + lq * 4 < D);
     float *o = dst + (size_t)y0 * row_elems + (size_t)min(x0 + px, W - 1) * D + min(k0 + lq * 4, D - 4);
-    vec ring[WIN];
+    vec ring[WIN], suf[WIN], pre = 0.0f;        // suf, pre: van Herk state (unused otherwise)
 #pragma unroll
     for (int j = 0; j < WIN; j++)
-        ring[j] = 0.0f;
-    // PadCosts flags of this thread's four levels (they do not depend on the row)
-    bool padded[4] = {false, false, false, false};
-    if constexpr (WTA) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int xm = x0 + px + pw.disp0 + (k0 + lq * 4 + e) * pw.dstep;
-            padded[e] = (unsigned)xm >= (unsigned)W;
-        }
-    }
+        ring[j] = suf[j] = 0.0f;
     int buf = 0;
     const int ylast = y1 - 1 + PR;
     gload(y0 + PL + 1);
@@ -298,7 +285,10 @@ __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restri
     #pragma unroll
                 for (int j = 0; j < WIN; j++)
                     w[j] = lds[buf][(px + j) * 8 + lq];
-                if constexpr (OP::SYMMETRIC) {
+                if constexpr (OP::VANHERK) {
+                    ring[rr] = OP::h(w);
+                    pre = rr == 0 ? ring[0] : vmin<4>(pre, ring[rr]);
+                } else if constexpr (OP::SYMMETRIC) {
                     ring[rr] = OP::h(w);
                 } else {
     #pragma unroll
@@ -307,43 +297,27 @@ __global__ __launch_bounds__(TX * 8) void tile_walk_kernel(const float *__restri
                     ring[WIN - 1] = OP::h(w);
                 }
                 if (yy - PR >= y0) {
-                    if constexpr (!WTA) {
-                        if (live)
-                            vstore<4>(o, OP::v(ring));
-                        o += row_elems;
-                    } else {
-                        const vec v = OP::v(ring);
-                        int sb = 0x7FFFFFFF, sd = 0x7FFFFFFF;
-                        if (live) {
-                            float bc = padded[0] ? pw.outside : v[0];
-                            int be = 0;
-    #pragma unroll
-                            for (int e = 1; e < 4; e++) {
-                                float c = padded[e] ? pw.outside : v[e];
-                                if (c < bc) {               // strict: the lowest level wins inside the lane
-                                    bc = c;
-                                    be = e;
-                                }
-                            }
-                            sb = ordered_bits(bc);
-                            sd = pw.d_first + k0 + lq * 4 + be;
-                        }
-                        seg8_min_to_first(sb, sd);
-                        if (lq == 0 && x0 + px < W)
-                            atomicMin(pw.keys + (size_t)(x0 + px) * H + (yy - PR), make_key(sb, sd));
-                    }
+                    // window of output row yy - PR = rows yy - WIN + 1 .. yy: suffix rr + 1 .. WIN - 1 of the
+                    // previous group and prefix 0 .. rr of this one
+                    vec v;
+                    if constexpr (OP::VANHERK)
+                        v = rr == WIN - 1 ? pre : vmin<4>(suf[rr == WIN - 1 ? 0 : rr + 1], pre);
+                    else
+                        v = OP::v(ring);
+                    if (live)
+                        vstore<4>(o, v);
+                    o += row_elems;
                 }
                 buf ^= 1;
             }
         }
+        if constexpr (OP::VANHERK) {            // suffix minima of the group just completed
+            suf[WIN - 1] = ring[WIN - 1];
+#pragma unroll
+            for (int j = WIN - 2; j >= 1; j--)
+                suf[j] = vmin<4>(ring[j], suf[j + 1]);
+        }
     }
-}
-
-__global__ void fill_keys_kernel(long long *keys, size_t n, long long value)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        keys[i] = value;
 }
 
 }  // namespace smk

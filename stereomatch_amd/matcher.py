@@ -80,7 +80,11 @@ class StereoMatcher(StereoParameters):
     def _derive(self, shape):
         # StereoMatcher.cpp:60-82
         h, w, nb = shape
-        if self.disp_step <= 0:
+        step = float(np.float32(self.disp_step))        # the reference's disp_step is a float
+        min_precision = float(np.float32(1e-3))
+        if (step <= 0.0
+                or (step < 1.0 and abs(1.0 / step - _round(1.0 / step)) > min_precision)
+                or (step > 1.0 and abs(step - _round(step)) > min_precision)):
             raise ValueError("ComputeCorrespondence: disp_step must integer N or 1.0/N")
         self.m_frame_diff_sign = 1 if self.frame_match - self.frame_ref > 0 else -1
         self.m_disp_num = 1 if self.disp_step < 1.0 else _round(self.disp_step)

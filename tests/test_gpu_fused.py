@@ -182,10 +182,12 @@ def test_fused_box_dsi(gpu_ctx, oracle, w, h, b, D, win, sign, fn, mmax, interva
         wd, wb = oracle.wta(oracle.pad_costs(oracle.min_filter(want, mf), po))
         keys = gpu_ctx.alloc(w * h * 8)
         disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
-        gpu_ctx.min_pad_wta_keys(cost, w * D, p, mf, 0, D, keys)
-        gpu_ctx.keys_decode(keys, w, h, disp, best)
-        assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
-        util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "min+pad+wta best")
+        for tseg in (-1, 8, 64):                 # the library's segment length, the shortest, the longest
+            with gpu_ctx.options(tseg=tseg):
+                gpu_ctx.min_pad_wta_keys(cost, w * D, p, mf, 0, D, keys)
+            gpu_ctx.keys_decode(keys, w, h, disp, best)
+            assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
+            util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "min+pad+wta best")
     # a disparity slab of the same volume
     d0, n = 8, D - 12 - (D - 12) % 4
     if n >= 33:
@@ -201,6 +203,26 @@ def test_fused_box_dsi(gpu_ctx, oracle, w, h, b, D, win, sign, fn, mmax, interva
         gd, gb = sharding.decode_keys(k)
         assert np.array_equal(gd, wd + d0)
         util.assert_bit_equal(gb, wb, "slab keys")
+
+
+@pytest.mark.parametrize("w, h, D, sign", [(130, 150, 40, 1), (57, 65, 96, -1), (56, 64, 4, 1), (300, 17, 68, 1)])
+@pytest.mark.parametrize("mf", [3, 5, 7, 9, 11])
+def test_min_pad_wta_keys_windows(gpu_ctx, oracle, w, h, D, sign, mf):
+    """smhip_min_pad_wta_keys for every window on shapes that cut its tiles: several pixel tiles and row
+    segments, level counts that are not a multiple of the 32-level tile, a frame exactly one tile big,
+    both frame directions; costs with many ties (small integers), so the lowest-level rule decides."""
+    rng = np.random.default_rng(1000 * mf + D)
+    cost = rng.integers(0, 6, (h, w, D)).astype(np.float32)
+    fr, fm = (0, 1) if sign > 0 else (1, 0)
+    po = oracle.make_params(w, h, 1, disp_max=D - 1, frame_ref=fr, frame_match=fm)
+    wd, wb = oracle.wta(oracle.pad_costs(oracle.min_filter(cost, mf), po))
+    p = capi.match_params(w, h, 1, D, frame_diff_sign=sign)
+    d_cost, keys = gpu_ctx.upload(cost), gpu_ctx.alloc(w * h * 8)
+    disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
+    gpu_ctx.min_pad_wta_keys(d_cost, w * D, p, mf, 0, D, keys)
+    gpu_ctx.keys_decode(keys, w, h, disp, best)
+    assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
+    util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "best cost")
 
 
 def test_exp2_pipeline_fused_equals_staged(gpu_ctx, oracle):
