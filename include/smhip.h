@@ -208,6 +208,16 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
                  int w, int h, int n_bands, size_t row_elems, float disp_step, float disp_min,
                  int mode, float *d_fdisp);
 
+/* ComputeMatchQuality (StcEvaluate.cpp:760-833): d_final_cost = aggregated cost at the winner, taken from
+ * the parabola through its neighbours at the fractional offset of d_fdisp (quality_mode = eval_match_quality;
+ * 2: no interpolation), divided by norm_bands (1, or 3 for colour: :774) and square-rooted when take_sqrt
+ * (match_fn == eSD, :830); d_certainty = the parabola's curvature, 0 where it is degenerate.  use_fit
+ * (aggr_subpixel): both are read from the fitted volumes d_cost / d_cert instead (:795-800). */
+int smhip_match_quality(smhip_ctx *ctx, const float *d_cost, const float *d_cert, const float *d_fdisp,
+                        int w, int h, int n_bands, size_t row_elems, size_t cert_row_elems, float disp_min,
+                        float disp_step_inv, int quality_mode, int use_fit, int norm_bands, int take_sqrt,
+                        float *d_final_cost, float *d_certainty);
+
 /* OptSO (StcOptSO.cpp:30-154): per scan-line, the path through the DSI that minimises data cost +
  * Potts smoothness, with the horizontal weights of ComputeSmoothnessCosts (StcOptimize.cpp:61-116)
  * taken from the reference image.  Same winners as the reference's O(D^2) scan (first strict

@@ -140,6 +140,9 @@ def lib():
         L.smo_refine.argtypes = [fp, fp, i32, C.c_int, C.c_int, C.c_int, C.c_long, C.c_float,
                                  C.c_int, C.c_int, fp]
         L.smo_preprocess_blur.argtypes = [u8, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.smo_match_quality.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int,
+                                        C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
+        L.smo_match_quality.restype = None
         for name in ("smo_subpixel_fit", "smo_collapse", "smo_refine", "smo_preprocess_blur"):
             getattr(L, name).restype = None
         for name in ("smo_raw_costs", "smo_box_filter", "smo_min_filter", "smo_convolve_14641",
@@ -294,6 +297,19 @@ def refine(cost, mind, disp, step, disp_min, mode):
     lib().smo_refine(_fp(c), _fp(m) if m is not None else None, _i32(dd), w, h, d, w * d, step,
                      disp_min, mode, _fp(out))
     return out
+
+
+def match_quality(cost, cert, fdisp, disp_min, step_inv, quality_mode, use_fit, norm_bands, take_sqrt):
+    """ComputeMatchQuality: returns (final_cost, certainty), float32 [h][w]."""
+    c = np.ascontiguousarray(cost, np.float32)
+    h, w, d = c.shape
+    e = np.ascontiguousarray(cert, np.float32) if cert is not None else None
+    f = np.ascontiguousarray(fdisp, np.float32)
+    fc, ce = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    lib().smo_match_quality(_fp(c), _fp(e) if e is not None else None, _fp(f), w, h, d, w * d,
+                            e.shape[1] * e.shape[2] if e is not None else 0, disp_min, step_inv,
+                            quality_mode, 1 if use_fit else 0, norm_bands, 1 if take_sqrt else 0, _fp(fc), _fp(ce))
+    return fc, ce
 
 
 def preprocess_blur(img, iters):

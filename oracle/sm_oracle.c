@@ -624,6 +624,52 @@ void smo_refine(const float *cost, const float *mind, const int32_t *disp, int w
         }
 }
 
+/* ComputeMatchQuality, StcEvaluate.cpp:760-833: cost at the (sub-pixel) winner and a certainty
+ * (curvature of the parabola through the winner's neighbours), per pixel.  quality_mode is
+ * eval_match_quality (2: no sub-pixel interpolation, :791-792); use_fit = aggr_subpixel (:795-800:
+ * cost and certainty come from the fitted volumes; cert keeps its own row stride, the pixel stride is
+ * nb as in :784); norm_bands = 1 or 3 (:774), take_sqrt = match_fn == eSD (:830).  fdisp out of range
+ * would index outside the DSI in the reference; levels are clamped here (tests stay inside). */
+void smo_match_quality(const float *cost, const float *cert, const float *fdisp, int w, int h, int nb,
+                       long row_elems, long cert_row_elems, int disp_min, float step_inv,
+                       int quality_mode, int use_fit, int norm_bands, int take_sqrt,
+                       float *fcost, float *fcert)
+{
+    float d_offset = (float)disp_min;                                  /* :773 */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t i = (size_t)y * w + x;
+            const float *c = cost + (size_t)y * row_elems + (size_t)x * nb;
+            float d_new = fdisp[i];
+            float d_sub = (d_new - d_offset) * step_inv;               /* :788 */
+            int d = (int)(d_sub + 0.5);                                /* :789 */
+            float x0 = d_sub - d;                                      /* :790 */
+            if (quality_mode == 2)
+                x0 = 0.0;
+            d = d < 0 ? 0 : (d > nb - 1 ? nb - 1 : d);
+            if (use_fit) {
+                fcost[i] = c[d];                                       /* :797-799 */
+                fcert[i] = cert[(size_t)y * cert_row_elems + (size_t)x * nb + d];
+            } else {
+                int d_min = d + (d == 0) - (d == nb - 1);              /* :805 */
+                float c0 = c[d_min - 1], c1 = c[d_min], c2 = c[d_min + 1];
+                float a = 0.5 * (c0 - 2.0 * c1 + c2);                  /* :809-810 */
+                float b = 0.5 * (c2 - c0);
+                if (a <= 0.0 || a < 0.5 * fabs(b)) {                   /* :813-817 */
+                    fcost[i] = c1;
+                    fcert[i] = 0.0f;
+                } else {
+                    float ffit = a * x0 * x0 + b * x0 + c1;            /* :822 */
+                    fcost[i] = ffit;
+                    fcert[i] = a;
+                }
+            }
+            float favg = fcost[i] / norm_bands;                        /* :829-831 */
+            float fnew = take_sqrt ? (float)sqrt(favg) : favg;
+            fcost[i] = fnew;
+        }
+}
+
 /* StereoMatcher.cpp:177 via Convert.cpp:25-53: float -> uchar, clip, truncate */
 void smo_depth_from_float(const float *fdisp, int n, const smo_params *p, uint8_t *depth)
 {

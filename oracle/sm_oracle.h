@@ -121,6 +121,12 @@ void smo_collapse(const float *cost1, const float *mind1, int w, int h, int nb1,
 void smo_refine(const float *cost, const float *mind, const int32_t *disp, int w, int h, int nb,
                 long row_elems, float step, int disp_min, int mode, float *fdisp);
 
+/* StcEvaluate.cpp:760-833 (ComputeMatchQuality): final cost and certainty at the winner */
+void smo_match_quality(const float *cost, const float *cert, const float *fdisp, int w, int h, int nb,
+                       long row_elems, long cert_row_elems, int disp_min, float step_inv,
+                       int quality_mode, int use_fit, int norm_bands, int take_sqrt,
+                       float *fcost, float *fcert);
+
 /* StereoMatcher.cpp:177 */
 void smo_depth_from_float(const float *fdisp, int n, const smo_params *p, uint8_t *depth);
 

@@ -9,6 +9,7 @@
 // predict_err_* and the frames' resampled images.  Not restated: match quality (:760-863) and the
 // status statistics (:865-954; WTA leaves no status map).
 #include "StereoMatcher.h"
+#include "ImageIO.h"
 #include "Error.h"
 #include <cmath>
 #include <vector>
@@ -449,6 +450,52 @@ void CStereoMatcher::ComputePredictionErrors()
     }
 }
 
+// ComputeMatchQuality (StcEvaluate.cpp:760-863): cost and certainty at the winner, computed by
+// smhip_match_quality on the DSI that is still resident on the device; with verbose >= eVerboseDumpFiles
+// the two images go to reprojected/final_cost.pgm (x16) and reprojected/certainty.pgm (x0.5) as in
+// :836-846.  The cost histograms of :848-861 are not drawn.
+void CStereoMatcher::ComputeMatchQuality()
+{
+    if (m_used_fused || m_keys_done || !m_dev[B_COST])
+        throw CError("ComputeMatchQuality: the aggregated DSI is not available");
+    const int w = m_mp.width, h = m_mp.height;
+    const size_t wbytes = (size_t)w * sizeof(float);
+    DeviceBuffer(B_FDISP, wbytes * h);
+    DeviceBuffer(B_FCOST, wbytes * h);
+    DeviceBuffer(B_FCERT, wbytes * h);
+    Check(smhip_memcpy2d_h2d(m_ctx, m_dev[B_FDISP], wbytes, m_float_disparity.Data(),
+                             m_float_disparity.RowBytes(), wbytes, h));
+    const int norm_bands = m_reference.Shape().nBands == 1 ? 1 : 3;              // :774
+    Check(smhip_match_quality(m_ctx, (const float *)m_dev[B_COST],
+                              aggr_subpixel ? (const float *)m_dev[B_CERT] : nullptr, (const float *)m_dev[B_FDISP],
+                              w, h, m_disp_n, m_row_elems, m_cert_row_elems, (float)disp_min, m_disp_step_inv,
+                              eval_match_quality, aggr_subpixel != 0, norm_bands, match_fn == eSD,
+                              (float *)m_dev[B_FCOST], (float *)m_dev[B_FCERT]));
+    m_final_cost.ReAllocate(CShape(w, h, 1));
+    m_certainty.ReAllocate(CShape(w, h, 1));
+    Check(smhip_memcpy2d_d2h(m_ctx, m_final_cost.Data(), m_final_cost.RowBytes(), m_dev[B_FCOST], wbytes, wbytes, h));
+    Check(smhip_memcpy2d_d2h(m_ctx, m_certainty.Data(), m_certainty.RowBytes(), m_dev[B_FCERT], wbytes, wbytes, h));
+    if (verbose < eVerboseDumpFiles)
+        return;
+    fprintf(stderr, "Writing final_cost.pgm and certainty.pgm\n");
+    CByteImage fc(w, h, 1);
+    const struct { const CFloatImage *img; float scale; const char *name; } dumps[] = {
+        {&m_final_cost, 16.0f, "reprojected/final_cost.pgm"}, {&m_certainty, 0.5f, "reprojected/certainty.pgm"}};
+    for (const auto &d : dumps) {
+        for (int y = 0; y < h; y++) {
+            const float *src = d.img->Row(y);
+            uchar *dst = fc.Row(y);
+            for (int x = 0; x < w; x++) {                     // ScaleAndOffset float -> uchar, Convert.cpp:33-45
+                float v = src[x] * d.scale + 0.0f;
+                v = v < 0.0f ? 0.0f : v;
+                v = v > 255.0f ? 255.0f : v;
+                dst[x] = (uchar)v;
+            }
+        }
+        WriteImage(fc, d.name);
+    }
+}
+
 void CStereoMatcher::Evaluate()
 {
     // StcEvaluate.cpp:957-984
@@ -460,6 +507,10 @@ void CStereoMatcher::Evaluate()
     ComputeDisparityErrors();
     if (eval_predict_type != 0)
         ComputePredictionErrors();
+    if (eval_match_quality && !evaluate_only)                 // :977-979
+        ComputeMatchQuality();
+    // ComputeStatusErrors (:865-954) needs the status map that only OptSymmetric writes (out of scope,
+    // SURVEY 8): on this path m_status is empty and the reference skips it as well (:982-983).
     if (verbose >= eVerboseSummary)
         fprintf(stderr, "\n");
 }

@@ -421,6 +421,7 @@ void CStereoMatcher::AggrSubPixelFit()
                              m_disp_n, m_row_elems, m_match_outside));
     SwapCost();
     m_have_mind = true;
+    m_cert_row_elems = m_row_elems;
 }
 
 void CStereoMatcher::AggrCollapse()
@@ -434,14 +435,15 @@ void CStereoMatcher::AggrCollapse()
     size_t re2 = (size_t)m_mp.width * n2;
     size_t bytes2 = re2 * m_mp.height * sizeof(float);
     // collapsed cost and offsets go to the spare slots, then take the places of m_cost / m_sub_pixel_min
+    // (m_sub_pixel_cert stays as it is: the reference does not collapse it, StcEvaluate.cpp:782-799 reads it later)
     DeviceBuffer(B_COST2, bytes2);
-    DeviceBuffer(B_CERT, bytes2);
+    DeviceBuffer(B_MIND2, bytes2);
     Check(smhip_collapse(m_ctx, (const float *)m_dev[B_COST], m_have_mind ? (const float *)m_dev[B_MIND] : nullptr,
                          m_mp.width, m_mp.height, m_disp_n, m_row_elems, df, n2, re2, disp_step,
-                         (float *)m_dev[B_COST2], (float *)m_dev[B_CERT]));
+                         (float *)m_dev[B_COST2], (float *)m_dev[B_MIND2]));
     SwapCost();
-    std::swap(m_dev[B_MIND], m_dev[B_CERT]);
-    std::swap(m_dev_bytes[B_MIND], m_dev_bytes[B_CERT]);
+    std::swap(m_dev[B_MIND], m_dev[B_MIND2]);
+    std::swap(m_dev_bytes[B_MIND], m_dev_bytes[B_MIND2]);
     m_have_mind = true;
     m_disp_step = m_disp_step_inv = 1.0f;                     // :145-146
     m_disp_n = n2;

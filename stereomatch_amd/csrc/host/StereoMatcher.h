@@ -44,6 +44,7 @@ protected:
     void ComputeDisparityDiscont();
     void ComputeDisparityErrors();
     void ComputePredictionErrors();
+    void ComputeMatchQuality();
     void ComputePredictionError(CByteImage &predicted, const CByteImage &original, float &rms_error,
                                 float &fraction_visible);
     void BoxFilterOnDevice(CFloatImage &img, int window, bool average);
@@ -70,8 +71,10 @@ protected:
     CFloatImage m_float_disparity;
     CFloatImage m_true_disparity;       // ground truth / disp_scale + disp_min (StereoMatcher.cpp:121-130)
     CByteImage m_occlusion, m_textureless, m_depth_discont;
+    CFloatImage m_final_cost, m_certainty;   // ComputeMatchQuality: cost / certainty at the winner
+    size_t m_cert_row_elems = 0;        // row stride of m_sub_pixel_cert (it is not collapsed with the DSI)
     size_t m_row_elems = 0;
-    enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_MIND, B_CERT, B_FDISP, B_KEYS, B_COUNT };
+    enum { B_REF, B_MTC, B_COST, B_COST2, B_COST0, B_DISP, B_BEST, B_MIND, B_MIND2, B_CERT, B_FDISP, B_KEYS, B_FCOST, B_FCERT, B_COUNT };
     void *m_dev[B_COUNT];
     size_t m_dev_bytes[B_COUNT];
     std::vector<CStereoFrame> m_frame;

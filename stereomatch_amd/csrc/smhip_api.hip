@@ -1001,6 +1001,31 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
     return SMHIP_OK;
 }
 
+int smhip_match_quality(smhip_ctx *ctx, const float *d_cost, const float *d_cert, const float *d_fdisp,
+                        int w, int h, int nb, size_t row_elems, size_t cert_row_elems, float disp_min,
+                        float disp_step_inv, int quality_mode, int use_fit, int norm_bands, int take_sqrt,
+                        float *d_final_cost, float *d_certainty)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    if (!d_fdisp || !d_final_cost || !d_certainty)
+        return fail(SMHIP_EINVAL, "ComputeMatchQuality: null argument");
+    if (nb < 3 && !use_fit)
+        return fail(SMHIP_EINVAL, "ComputeMatchQuality: the parabola needs 3 disparity levels (%d given)", nb);
+    if (use_fit && (!d_cert || cert_row_elems < (size_t)w * nb))
+        return fail(SMHIP_EINVAL, "ComputeMatchQuality: aggr_subpixel needs the certainty volume");
+    if (norm_bands != 1 && norm_bands != 3)
+        return fail(SMHIP_EINVAL, "ComputeMatchQuality: costs are normalised by 1 or 3 bands (%d given)", norm_bands);
+    long n_pix = (long)w * h;
+    smk::match_quality_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        d_cost, d_cert, d_fdisp, w, h, nb, row_elems, cert_row_elems, disp_min, disp_step_inv,
+        quality_mode == 2, use_fit != 0, norm_bands, take_sqrt != 0, d_final_cost, d_certainty);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
 int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t row_elems,
                  const uint8_t *d_ref, size_t img_pitch, int img_bands, float opt_smoothness,
                  float opt_grad_thresh, float opt_grad_penalty, int32_t *d_disp, float *d_best)

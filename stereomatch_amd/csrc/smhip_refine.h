@@ -117,4 +117,47 @@ __global__ void refine_kernel(const float *__restrict__ cost, const float *__res
     fdisp[p] = f;
 }
 
+// ComputeMatchQuality (StcEvaluate.cpp:760-833): per pixel the aggregated cost at the (sub-pixel) winner
+// -- the parabola through the winner's neighbours evaluated at the fractional offset of the float
+// disparity -- and its curvature as a certainty; the cost is divided by the number of colour bands and,
+// for squared differences, square-rooted (:829-831).  use_fit (aggr_subpixel): both come from the fitted
+// volumes (:795-800; cert is indexed with the pixel stride D and its own row stride, as the reference does
+// after a collapse).  The level is clamped into the DSI (the reference would read outside it).
+__global__ void match_quality_kernel(const float *__restrict__ cost, const float *__restrict__ cert,
+                                     const float *__restrict__ fdisp, int W, int H, int D, size_t row_elems,
+                                     size_t cert_row_elems, float d_offset, float step_inv, int no_interp,
+                                     int use_fit, int norm_bands, int take_sqrt, float *__restrict__ fcost,
+                                     float *__restrict__ fcert)
+{
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= (long)W * H)
+        return;
+    int y = (int)(p / W), x = (int)(p - (long)y * W);
+    const float *c = cost + (size_t)y * row_elems + (size_t)x * D;
+    float d_sub = (fdisp[p] - d_offset) * step_inv;                  // :788
+    int d = (int)((double)d_sub + 0.5);                              // :789
+    float x0 = no_interp ? 0.0f : d_sub - (float)d;                  // :790-792
+    d = min(max(d, 0), D - 1);
+    float fc, ce;
+    if (use_fit) {
+        fc = c[d];
+        ce = cert[(size_t)y * cert_row_elems + (size_t)x * D + d];
+    } else {
+        int dm = d + (d == 0) - (d == D - 1);
+        float c0 = c[dm - 1], c1 = c[dm], c2 = c[dm + 1];
+        float a, b;
+        parabola(c0, c1, c2, a, b);
+        if (parabola_ok(a, b)) {
+            fc = a * x0 * x0 + b * x0 + c1;                          // :822, float arithmetic, no contraction
+            ce = a;
+        } else {
+            fc = c1;
+            ce = 0.0f;
+        }
+    }
+    float favg = fc / (float)norm_bands;
+    fcost[p] = take_sqrt ? (float)sqrt((double)favg) : favg;
+    fcert[p] = ce;
+}
+
 }  // namespace smk

@@ -305,6 +305,7 @@ class StereoMatcher(StereoParameters):
                        self.m_row_elems, self.m_match_outside)
         self._bufs["cost"], self._bufs["cost2"] = other, self.d_cost
         self.d_cost = other
+        self.m_cert_row_elems = self.m_row_elems         # m_sub_pixel_cert is not collapsed later
 
     def AggrCollapse(self):  # StcAggregate.cpp:134-230
         if self.m_disp_step >= 1.0:
@@ -350,6 +351,24 @@ class StereoMatcher(StereoParameters):
         c.refine(self.d_disp, self.d_cost, self.d_mind if mode == 1 else None, p.width, p.height,
                  self.m_disp_n, self.m_row_elems, float(self.m_disp_step), float(self.disp_min), mode, d_f)
         return c.download(d_f, (p.height, p.width), np.float32)
+
+    def ComputeMatchQuality(self):  # StcEvaluate.cpp:760-833, on the resident DSI
+        """(final_cost, certainty) float32 [H, W] for the last ComputeCorrespondence; needs
+        eval_match_quality 1 or 2 (it keeps the DSI: no fused route)."""
+        if not self.eval_match_quality or self.used_fused or self.m_keys_done:
+            raise ValueError("ComputeMatchQuality: set eval_match_quality before ComputeCorrespondence")
+        p, c = self.m_params, self.ctx
+        n = p.width * p.height * 4
+        d_f, d_fc, d_ce = self._buf("fdisp", n), self._buf("fcost", n), self._buf("fcert", n)
+        fd = np.ascontiguousarray(self.m_float_disparity, np.float32)
+        c._chk(c.L.smhip_memcpy_h2d(c.h, d_f.ptr, fd.ctypes.data, fd.nbytes))
+        inv = float(np.float32(self.m_disp_den) / np.float32(self.m_disp_num)) if self.m_disp_step != 1.0 else 1.0
+        c.match_quality(self.d_cost, self.d_cert if self.aggr_subpixel else None, d_f, p.width, p.height,
+                        self.m_disp_n, self.m_row_elems, self.m_cert_row_elems if self.aggr_subpixel else 0,
+                        float(self.disp_min), inv, self.eval_match_quality, bool(self.aggr_subpixel),
+                        1 if p.n_bands == 1 else 3, self.match_fn == 2, d_fc, d_ce)
+        return (c.download(d_fc, (p.height, p.width), np.float32),
+                c.download(d_ce, (p.height, p.width), np.float32))
 
     def _scale_and_offset(self, disp):  # StcRefine.cpp:34-39 (Convert.cpp:31-40)
         f32 = np.float32

@@ -310,6 +310,21 @@ def test_subpixel_fit_collapse_refine(gpu_ctx, oracle, h, w, d):
                                   oracle.refine(wc, wm, disp, step, dmn, mode), "refine %d" % mode)
     with pytest.raises(capi.SmhipError):
         gpu_ctx.collapse(dst, dmin, w, h, d, w * d, 2, d, w * d, 0.5, dst, dmin)
+    # ComputeMatchQuality (StcEvaluate.cpp:760-833) on the fitted volume: parabola at the refined winner,
+    # no interpolation (eval_match_quality 2), the aggr_subpixel route, 1 / 3 bands, with and without sqrt
+    fcost, fcert = gpu_ctx.alloc(h * w * 4), gpu_ctx.alloc(h * w * 4)
+    for step, dmn in ((1.0, 0), (0.5, 3)):
+        fdisp = oracle.refine(wc, wm, disp, step, dmn, 2)
+        fd = up(gpu_ctx, fdisp)
+        inv = float(np.float32(1.0) / np.float32(step))
+        for qmode, use_fit, nbands, sq in ((1, 0, 1, 0), (2, 0, 3, 1), (1, 1, 3, 0), (1, 0, 3, 1)):
+            gpu_ctx.match_quality(dst, dcert if use_fit else None, fd, w, h, d, w * d, w * d, float(dmn), inv,
+                                  qmode, use_fit, nbands, sq, fcost, fcert)
+            oc, oe = oracle.match_quality(wc, we if use_fit else None, fdisp, dmn, inv, qmode, use_fit, nbands, sq)
+            util.assert_bit_equal(gpu_ctx.download(fcost, (h, w), np.float32), oc, "final cost %r" % ((qmode, use_fit),))
+            util.assert_bit_equal(gpu_ctx.download(fcert, (h, w), np.float32), oe, "certainty %r" % ((qmode, use_fit),))
+    with pytest.raises(capi.SmhipError, match="certainty volume"):
+        gpu_ctx.match_quality(dst, None, fd, w, h, d, w * d, w * d, 0.0, 1.0, 1, 1, 1, 0, fcost, fcert)
 
 
 @pytest.mark.parametrize("h,w,d,pad", [(9, 21, 8, 0), (150, 70, 12, 0), (70, 150, 40, 4), (3, 5, 4, 0),
