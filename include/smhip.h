@@ -153,7 +153,7 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst,
  * it to E0 (:182-191).  TOLERANCE MODE -- the only operator here that is not bit-exact: exp and
  * log come from the device's math library (about 1 ulp from the host's), everything else follows
  * the reference's order of operations in the reference's precisions. */
-#define SMHIP_BAYES_MAX_LEVELS 128
+#define SMHIP_BAYES_MAX_LEVELS 512
 int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_cost0, int w, int h,
                         int n_bands, size_t row_elems, float scale_cost, float mu, float sigmaP,
                         float epsP, int iter);

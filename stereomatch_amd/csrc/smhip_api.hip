@@ -20,6 +20,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 namespace {
 
@@ -1104,6 +1105,9 @@ int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
 
 namespace {
 
+// levels per lane of the smoothing kernel: 1, 2, 4 or 8 (64 ... 512 levels)
+int bayes_slots(int nb) { return nb <= 64 ? 1 : nb <= 128 ? 2 : nb <= 256 ? 4 : 8; }
+
 // w(d, d') = rhoP(d - d') / row sum, on the host as the reference computes it (:209-222), then the
 // band (w - e_d) and e_d = epsP / s_d the kernel sums (see smhip_bayes.h); cached per context
 int bayes_prepare(smhip_ctx *ctx, const float *d_cost, const float *d_cost2, const float *d_cost0, int w, int h,
@@ -1119,7 +1123,7 @@ int bayes_prepare(smhip_ctx *ctx, const float *d_cost, const float *d_cost2, con
         return fail(SMHIP_EINVAL, "Bayesian diffusion: at most %d disparity levels (%d given)",
                     SMHIP_BAYES_MAX_LEVELS, nb);
     static_assert(SMHIP_BAYES_MAX_LEVELS == smk::BAYES_MAXD, "header and kernel limits differ");
-    const int DP = nb <= 64 ? 64 : 128;
+    const int DP = bayes_slots(nb) * 64;
     const size_t band_cap = (size_t)(2 * SMHIP_BAYES_MAX_LEVELS - 1) * SMHIP_BAYES_MAX_LEVELS;
     if (ctx->bayes_n == nb && ctx->bayes_sigma == sigmaP && ctx->bayes_eps == epsP)
         return SMHIP_OK;
@@ -1136,7 +1140,8 @@ int bayes_prepare(smhip_ctx *ctx, const float *d_cost, const float *d_cost2, con
         if (!(r == epsP))
             B = d;
     }
-    double *band = ctx->bayes_wh, *ed = band + band_cap, row[SMHIP_BAYES_MAX_LEVELS];
+    double *band = ctx->bayes_wh, *ed = band + band_cap;
+    std::vector<double> row(nb);
     memset(band, 0, cap);
     for (int d = 0; d < nb; d++) {
         float s = 0.0;
@@ -1169,19 +1174,25 @@ void bayes_smooth(smhip_ctx *ctx, float *e, float *es_out, float *e0_init, float
     const size_t band_cap = (size_t)(2 * SMHIP_BAYES_MAX_LEVELS - 1) * SMHIP_BAYES_MAX_LEVELS;
     long n_pix = (long)w * h;
     unsigned blocks = (unsigned)((n_pix + 3) / 4 < 4096 ? (n_pix + 3) / 4 : 4096);
-    const bool narrow = ctx->bayes_band <= 6;        // sigmaP up to about 0.5: the band lives in registers
-    const bool two = nb > 64;
+    const int slots = bayes_slots(nb);
+    // sigmaP up to about 0.5: the band lives in registers (one or two levels per lane only: 13 doubles each)
+    const bool narrow = ctx->bayes_band <= 6 && slots <= 2;
+    const size_t lds = (size_t)4 * 3 * 64 * slots * sizeof(double);
 #define LAUNCH_BS(S, HB)                                                                                    \
     do {                                                                                                    \
-        if (es_in) smk::bayes_smooth_kernel<S, HB, true><<<blocks, 256, 0, ctx->stream>>>(                  \
+        if (es_in) smk::bayes_smooth_kernel<S, HB, true><<<blocks, 256, lds, ctx->stream>>>(                \
             nullptr, es_out, e0, 0.0f, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h, nb,    \
             row_elems, es_in, mu);                                                                          \
-        else smk::bayes_smooth_kernel<S, HB, false><<<blocks, 256, 0, ctx->stream>>>(                       \
+        else smk::bayes_smooth_kernel<S, HB, false><<<blocks, 256, lds, ctx->stream>>>(                     \
             e, es_out, e0_init, scale_cost, ctx->bayes_w, ctx->bayes_w + band_cap, ctx->bayes_band, w, h,   \
             nb, row_elems);                                                                                 \
     } while (0)
-    if (!two) { if (narrow) LAUNCH_BS(1, 6); else LAUNCH_BS(1, 0); }
-    else      { if (narrow) LAUNCH_BS(2, 6); else LAUNCH_BS(2, 0); }
+    switch (slots) {
+    case 1: if (narrow) LAUNCH_BS(1, 6); else LAUNCH_BS(1, 0); break;
+    case 2: if (narrow) LAUNCH_BS(2, 6); else LAUNCH_BS(2, 0); break;
+    case 4: LAUNCH_BS(4, 0); break;
+    default: LAUNCH_BS(8, 0); break;
+    }
 #undef LAUNCH_BS
 }
 

@@ -15,7 +15,7 @@
 // 2B+1 terms instead of D (B = 5 for the reference's sigmaP 0.4; B = D-1, i.e. the full product,
 // when there is no such cut-off).  The host computes w as the reference does (:209-222), finds B
 // and uploads the band; the device sums it with FMAs in double.  One wave per pixel, lane l holds
-// levels l and l + 64 (D <= 128; the reference stops at 99, MAXDISP :200-202); the normalised
+// levels l, l + 64, ... (D <= 512; the reference stops at 99, MAXDISP :200-202); the normalised
 // probabilities go through a wave-private, zero-padded LDS line so lane d reads P(d+k).
 #pragma once
 
@@ -65,13 +65,14 @@ __device__ __forceinline__ double neg_log_f64(double x)
     return -fma((double)e, 0.6931471805599453, 2.0 * z * p);
 }
 
-constexpr int BAYES_MAXD = 128;          // == SMHIP_BAYES_MAX_LEVELS
-constexpr int BAYES_LINE = 3 * BAYES_MAXD;
+constexpr int BAYES_MAXD = 512;          // == SMHIP_BAYES_MAX_LEVELS
 
 // steps 1-3: E -> Es.  wb = band [(2B+1)][64*SLOTS] of (w - e_d), zero outside the matrix;
-// ed = e_d per level.  E0 != nullptr (first iteration): E *= scale first, and E0 = E (:182-191).
+// ed = e_d per level.  Lane l holds levels l, l + 64, ..., l + 64 (SLOTS - 1) (SLOTS = 1, 2, 4, 8: up to
+// 512 levels; the reference stops at 99).  E0 != nullptr (first iteration): E *= scale first, and
+// E0 = E (:182-191).
 // HB > 0: bands up to half-width HB are held in registers for the whole kernel (the weights
-// depend on the level only); HB = 0: any band, weights read in the loop.
+// depend on the level only; used for SLOTS <= 2); HB = 0: any band, weights read in the loop.
 // FUSED: E is not read but formed on the fly from the previous iteration's smoothed energies
 // EsIn, E = E0 + mu * (Es + left + right + up + down) -- step 4 of that iteration, the same float
 // expression as bayes_update_kernel -- so a run of iterations moves 12 instead of 20 bytes per voxel
@@ -85,21 +86,25 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
                                                            const float *__restrict__ EsIn = nullptr, float mu = 0.0f)
 {
     constexpr int DP = 64 * SLOTS;
-    __shared__ double line[4][BAYES_LINE];
+    constexpr int BASE = DP, LINE = 3 * DP;             // zero margins of DP on both sides (B < D <= DP)
+    extern __shared__ __attribute__((aligned(16))) double bayes_lines[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double *pl = line[wave];
-    for (int i = lane; i < BAYES_LINE; i += 64)
+    double *pl = bayes_lines + (size_t)wave * LINE;
+    for (int i = lane; i < LINE; i += 64)
         pl[i] = 0.0;
-    const int dA = lane, dB = lane + 64;
-    const bool inA = dA < D, inB = SLOTS > 1 && dB < D;
-    const double edA = inA ? ed[dA] : 0.0, edB = inB ? ed[dB] : 0.0;
-    double wA[2 * HB + 1], wB[2 * HB + 1];
+    bool in[SLOTS];
+    double edl[SLOTS];
+    double wr[SLOTS][2 * HB + 1];
 #pragma unroll
-    for (int j = 0; j < 2 * HB + 1; j++) {
-        const int k = j - HB;
-        const bool in = HB > 0 && k >= -B && k <= B;
-        wA[j] = in ? wb[(size_t)(k + B) * DP + dA] : 0.0;
-        wB[j] = in && SLOTS > 1 ? wb[(size_t)(k + B) * DP + dB] : 0.0;
+    for (int q = 0; q < SLOTS; q++) {
+        const int d = lane + 64 * q;
+        in[q] = d < D;
+        edl[q] = in[q] ? ed[d] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 2 * HB + 1; j++) {
+            const int k = j - HB;
+            wr[q][j] = (HB > 0 && k >= -B && k <= B) ? wb[(size_t)(k + B) * DP + d] : 0.0;
+        }
     }
     // wave-uniform walk over the pixels, (x, y) stepped without a division per pixel
     const int n_waves = (int)gridDim.x * 4, first = (int)blockIdx.x * 4 + wave;
@@ -112,65 +117,71 @@ __global__ __launch_bounds__(256) void bayes_smooth_kernel(float *__restrict__ E
             if (y >= H)
                 break;
         }
-        const size_t o = (size_t)y * row_elems + (size_t)x * D;
-        float eA = 0.0f, eB = 0.0f;
+        const size_t o = (size_t)y * row_elems + (size_t)x * D + lane;
+        float e[SLOTS];
         if constexpr (FUSED) {
             const long lf = x > 0 ? -(long)D : 0, rt = x < W - 1 ? (long)D : 0;
             const long up = y > 0 ? -(long)row_elems : 0, dn = y < H - 1 ? (long)row_elems : 0;
-            if (inA) {
-                const float *s = EsIn + o + dA;
-                eA = E0[o + dA] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
-            }
-            if (inB) {
-                const float *s = EsIn + o + dB;
-                eB = E0[o + dB] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
+#pragma unroll
+            for (int q = 0; q < SLOTS; q++) {
+                e[q] = 0.0f;
+                if (in[q]) {
+                    const float *s = EsIn + o + 64 * q;
+                    e[q] = E0[o + 64 * q] + mu * (s[0] + s[lf] + s[rt] + s[up] + s[dn]);
+                }
             }
         } else {
-            eA = inA ? E[o + dA] : 0.0f;
-            eB = inB ? E[o + dB] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < SLOTS; q++)
+                e[q] = in[q] ? E[o + 64 * q] : 0.0f;
         }
         if (!FUSED && E0) {
-            eA = eA * scale + 0.0f;
-            eB = eB * scale + 0.0f;
-            if (inA) E[o + dA] = E0[o + dA] = eA;
-            if (inB) E[o + dB] = E0[o + dB] = eB;
+#pragma unroll
+            for (int q = 0; q < SLOTS; q++) {
+                e[q] = e[q] * scale + 0.0f;
+                if (in[q])
+                    E[o + 64 * q] = E0[o + 64 * q] = e[q];
+            }
         }
-        double pA = inA ? (double)expf(-eA) : 0.0;          // :236
-        double pB = inB ? (double)expf(-eB) : 0.0;
-        const double s = wave_sum_f64(pA + pB);
-        if (s == 0) {                                       // :238-241
-            pA = inA ? 1.0 / D : 0.0;
-            pB = inB ? 1.0 / D : 0.0;
-        } else {
-            const double rs = fast_rcp_f64(s);
-            pA *= rs;
-            pB *= rs;
+        double pr[SLOTS], part = 0.0;
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++) {
+            pr[q] = in[q] ? (double)expf(-e[q]) : 0.0;       // :236
+            part += pr[q];
         }
+        const double s = wave_sum_f64(part);
+        const double rs = s == 0 ? 0.0 : fast_rcp_f64(s);
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++)
+            pr[q] = s == 0 ? (in[q] ? 1.0 / D : 0.0) : pr[q] * rs;   // :238-241
         __builtin_amdgcn_wave_barrier();                    // the previous pixel's reads are done
-        if (inA) pl[BAYES_MAXD + dA] = pA;
-        if (inB) pl[BAYES_MAXD + dB] = pB;
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++)
+            if (in[q])
+                pl[BASE + lane + 64 * q] = pr[q];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        double psA = edA, psB = edB;                        // :247-250, band + constant
+        double ps[SLOTS];                                   // :247-250, band + constant
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++)
+            ps[q] = edl[q];
         if (HB > 0) {
 #pragma unroll
-            for (int j = 0; j < 2 * HB + 1; j++) {
-                psA = fma(wA[j], pl[BAYES_MAXD + dA + j - HB], psA);
-                if (SLOTS > 1)
-                    psB = fma(wB[j], pl[BAYES_MAXD + dB + j - HB], psB);
-            }
+            for (int j = 0; j < 2 * HB + 1; j++)
+#pragma unroll
+                for (int q = 0; q < SLOTS; q++)
+                    ps[q] = fma(wr[q][j], pl[BASE + lane + 64 * q + j - HB], ps[q]);
         } else {
-            const double *wk = wb;
-            for (int k = -B; k <= B; k++, wk += DP) {
-                psA = fma(wk[dA], pl[BAYES_MAXD + dA + k], psA);
-                if (SLOTS > 1)
-                    psB = fma(wk[dB], pl[BAYES_MAXD + dB + k], psB);
-            }
+            const double *wk = wb + lane;
+            for (int k = -B; k <= B; k++, wk += DP)
+#pragma unroll
+                for (int q = 0; q < SLOTS; q++)
+                    ps[q] = fma(wk[64 * q], pl[BASE + lane + 64 * q + k], ps[q]);
         }
-        if (inA)
-            Es[o + dA] = (float)neg_log_f64(1e-16 > psA ? 1e-16 : psA);   // :253
-        if (inB)
-            Es[o + dB] = (float)neg_log_f64(1e-16 > psB ? 1e-16 : psB);
+#pragma unroll
+        for (int q = 0; q < SLOTS; q++)
+            if (in[q])
+                Es[o + 64 * q] = (float)neg_log_f64(1e-16 > ps[q] ? 1e-16 : ps[q]);   // :253
     }
 }
 

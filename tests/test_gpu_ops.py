@@ -435,7 +435,9 @@ BAYES_RTOL = 1e-5
 
 
 @pytest.mark.parametrize("h,w,d,pad", [(6, 20, 7, 0), (5, 9, 64, 3), (4, 11, 99, 0), (3, 7, 128, 0),
-                                       (3, 13, 65, 1), (1, 9, 16, 0), (7, 1, 5, 0), (2, 2, 2, 0)])
+                                       (3, 13, 65, 1), (1, 9, 16, 0), (7, 1, 5, 0), (2, 2, 2, 0),
+                                       (3, 6, 129, 0), (2, 5, 200, 1), (2, 7, 256, 0), (2, 4, 300, 0),
+                                       (1, 3, 512, 0)])
 @pytest.mark.parametrize("n_iter", [1, 5])
 @pytest.mark.parametrize("prior", [(0.4, 0.01), (3.0, 0.05), (1.5, 0.0), (30.0, 0.01)])
 def test_bayesian_iter(gpu_ctx, oracle, h, w, d, pad, n_iter, prior):
@@ -470,9 +472,9 @@ def test_bayesian_underflow_and_limits(gpu_ctx, oracle):
             gpu_ctx.bayesian_iter(b, es, e0, W, H, D, r, 1.0, 0.5, 0.4, 0.01, it)
     got = run_inplace(gpu_ctx, c, run)
     assert np.abs(got - want).max() <= BAYES_RTOL * np.abs(want).max()
-    big = gpu_ctx.alloc(2 * 2 * 129 * 4)
-    with pytest.raises(capi.SmhipError, match="at most 128"):
-        gpu_ctx.bayesian_iter(big, es, e0, 2, 2, 129, 2 * 129, 1.0, 0.5, 0.4, 0.01, 0)
+    big = gpu_ctx.alloc(2 * 2 * 513 * 4)
+    with pytest.raises(capi.SmhipError, match="at most 512"):
+        gpu_ctx.bayesian_iter(big, es, e0, 2, 2, 513, 2 * 513, 1.0, 0.5, 0.4, 0.01, 0)
     with pytest.raises(capi.SmhipError, match="distinct"):
         gpu_ctx.bayesian_iter(es, es, e0, w, h, d, w * d, 1.0, 0.5, 0.4, 0.01, 0)
 
@@ -504,7 +506,7 @@ def test_opt_dp(gpu_ctx, oracle, h, w, d, b, par):
 
 
 @pytest.mark.parametrize("h,w,d,pad", [(6, 20, 7, 0), (5, 9, 64, 3), (4, 11, 99, 0), (3, 7, 128, 0), (1, 9, 16, 0),
-                                       (7, 1, 5, 0), (40, 70, 33, 1)])
+                                       (7, 1, 5, 0), (40, 70, 33, 1), (3, 9, 200, 0), (2, 5, 400, 1)])
 @pytest.mark.parametrize("n_iter", [0, 1, 2, 3, 6])
 def test_bayesian_run_equals_iterations(gpu_ctx, h, w, d, pad, n_iter):
     """smhip_bayesian_run (energies formed inside the smoothing kernel between iterations) gives the
