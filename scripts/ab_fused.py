@@ -2,6 +2,7 @@
 """A/B timing of the fused pair at config 3 (or --width/--height/--levels/--first) under context options:
 pass A / pass B event times as bench.py records them.  GPU box only."""
 import argparse
+import json
 import os
 import sys
 
@@ -16,6 +17,7 @@ ap.add_argument("--levels", type=int, default=256)
 ap.add_argument("--total", type=int, default=0)
 ap.add_argument("--first", type=int, default=0)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--opts", nargs="+", default=["{}", '{"float_a": 0}'], help="option sets as JSON objects")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.levels
 D = args.total or n
@@ -39,7 +41,7 @@ def step():
 
 ref = None
 for rep in range(2):
-    for opts in ({"float_a": 0, "keybuf": 0}, {}, {"keybuf": 12}, {"keybuf": 24}, {"keybuf": 32}, {"keybuf": 48}):
+    for opts in [json.loads(o) for o in args.opts]:
         with ctx.options(**opts):
             for _ in range(5):
                 step()

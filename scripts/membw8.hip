@@ -55,5 +55,11 @@ int main(int argc, char **argv)
                          : timeit([&] { read_B<f2><<<(W + 3) / 4, 256>>>(a, W, H, Dp, TY, o); });
     printf("%dx%d x %d levels: write-only (pass A order) %.3f ms %5.0f GB/s (%.3f of 8 TB/s) | read-only (pass B order) %.3f ms %5.0f GB/s (%.3f)\n",
            W, H, Dp, tw, B / tw / 1e6, B / tw / 8e9, tr, B / tr / 1e6, B / tr / 8e9);
+    if (Dp == 128) {
+        // two consecutive rows of a 128-level column are adjacent in the slab: one 1-KiB load per row PAIR
+        // is the address stream of a 256-level slab with half the rows and 16-row bands
+        float tp = timeit([&] { read_B<f4><<<(W + 3) / 4, 256>>>(a, W, H / 2, 256, TY / 2, o); });
+        printf("read-only, row pairs (1 KiB per wave load): %.3f ms %5.0f GB/s (%.3f)\n", tp, B / tp / 1e6, B / tp / 8e9);
+    }
     return 0;
 }

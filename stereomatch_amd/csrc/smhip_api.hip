@@ -1308,6 +1308,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     int tyshift = tuned_a ? 5 : 0;
     if (tuned_a && ctx->opt[SMHIP_OPT_TYSHIFT] >= 0)
         tyshift = ctx->opt[SMHIP_OPT_TYSHIFT];           // (smhip_set_option keeps it within 0..8)
+    while (tyshift > 0 && ((((unsigned long long)W << tyshift) * (unsigned long long)Dp) >> 32) != 0)
+        tyshift--;                                      // pass B multiplies the band size as a 32-bit number
     size_t bands = ((size_t)H + (1u << tyshift) - 1) >> tyshift;
     size_t trow = (size_t)W * Dp;                       // floats per image row of T
     size_t t_elems = (bands << tyshift) * trow;

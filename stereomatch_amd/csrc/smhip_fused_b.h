@@ -74,13 +74,16 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     long long *kbuf = kbuf_all + (size_t)wib * kb_rows;
     int kb_first = 0;                                  // first row held in the LDS key buffer
 
-    bool padded[VPL], live[VPL];
+    bool padded[VPL], live[VPL], repl[VPL];
+    float replv[VPL];                                  // what PadCosts / the end of the slab put in the level's place
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         int k = k0 + i;
         live[i] = k < D;
         int xm = x + disp0 + (k < D ? k : D - 1) * dstep;
         padded[i] = (xm < 0) || (xm >= W);             // PadLine, StcRawCosts.cpp:451-456
+        repl[i] = padded[i] || !live[i];
+        replv[i] = live[i] ? outside : __builtin_inff();
     }
 
     // PadCosts replaces the aggregated cost of a padded (x, k) by `outside`, so the chains of
@@ -91,10 +94,19 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     for (int i = 0; i < VPL; i++)
         need = need || (live[i] && (STORE || !padded[i]));
     float *sout = STORE ? S + (size_t)x * D + (k0 < D ? k0 : 0) : nullptr;
+    // The kernel is bound by instruction issue as much as by HBM (VALU + SALU + s_nop slots per row against
+    // the bytes of a row), so the per-row instruction count matters: the row offset is one 32 x 32 -> 64 bit
+    // product, PadCosts and the end of the slab are one select per level, the key select takes its scalars
+    // without a copy.  The branch around the load stays: a form without it (idle lanes read one shared
+    // element) is 4 % faster when pass B runs alone (scripts/bench_b.hip) and 7 % slower behind pass A.
+    const unsigned band_elems = ((unsigned)W << tyshift) * (unsigned)Dp;     // (< 2^32: the launch sees to it)
+    const int tymask = (1 << tyshift) - 1;
     auto ld = [&](int row, float(&v)[VPL]) {
-        if (need)
-            load_row<VPL>(T + slab_row_offset(clampi(row, H), W, Dp, tyshift) + j, v);
-        else {
+        if (need) {
+            const int r = clampi(row, H);
+            const size_t off = (size_t)(unsigned)(r >> tyshift) * band_elems + (unsigned)((r & tymask) * Dp);
+            load_row<VPL>(T + off + j, v);
+        } else {
 #pragma unroll
             for (int i = 0; i < VPL; i++)
                 v[i] = 0.0f;
@@ -114,6 +126,31 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     }
 
     int key_lo = 0, key_hi = 0;
+    // one row: running sums, PadCosts, first minimum of the lane's levels -> ordered cost and its index
+    auto row_value = [&](const float(&od)[VPL], const float(&nw)[VPL], int &s, int &bi) {
+        float best = 0;
+        bi = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; i++) {
+            acc[i] = acc[i] + scale * (-od[i] + nw[i]);
+            const float v = repl[i] ? replv[i] : acc[i];
+            if (i == 0) {
+                best = v;
+            } else if (v < best) {                      // strict: lowest level wins inside the lane
+                best = v;
+                bi = i;
+            }
+        }
+        s = ordered_bits(best);
+    };
+    // the wave minimum m is known: lowest lane holding it, its level, key into the slot lane
+    auto row_key = [&](int s, int bi, int m, int slot) {
+        unsigned long long eq = __builtin_amdgcn_ballot_w64(s == m);
+        int wl = (int)__builtin_ctzll(eq);              // lowest lane with the minimum
+        int d = d_first + chunk * CH + wl * VPL + __builtin_amdgcn_readlane(bi, wl);
+        key_lo = (lane != slot) ? key_lo : d;           // (this way round the scalars need no copy to a VGPR)
+        key_hi = (lane != slot) ? key_hi : m;
+    };
     // slot = lane that keeps the key of this row
     auto step = [&](const float(&od)[VPL], const float(&nw)[VPL], int slot, int y) {
         if constexpr (STORE) {
@@ -127,33 +164,19 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                 *(typename vecf<VPL>::type *)(sout + (size_t)y * s_row_elems) = o;
             return;
         }
-        float best = 0;
-        int bi = 0;
-#pragma unroll
-        for (int i = 0; i < VPL; i++) {
-            acc[i] = acc[i] + scale * (-od[i] + nw[i]);
-            float v = padded[i] ? outside : acc[i];
-            v = live[i] ? v : __builtin_inff();
-            if (i == 0) {
-                best = v;
-            } else if (v < best) {                      // strict: lowest level wins inside the lane
-                best = v;
-                bi = i;
-            }
-        }
-        int s = ordered_bits(best);
+        int s, bi;
+        row_value(od, nw, s, bi);
         if (ABL & 1) {                                  // ablation: no wave reduction
             key_lo += bi;
             key_hi += s;
             return;
         }
         int m = wave_min_i32(s);
-        unsigned long long eq = __builtin_amdgcn_ballot_w64(s == m);
-        int wl = (int)__builtin_ctzll(eq);              // lowest lane with the minimum
-        int d = d_first + chunk * CH + wl * VPL + __builtin_amdgcn_readlane(bi, wl);
-        key_lo = (lane == slot) ? d : key_lo;
-        key_hi = (lane == slot) ? m : key_hi;
+        row_key(s, bi, m, slot);
     };
+    // (Two rows at once with their two DPP chains interleaved, so that one chain's step fills the other's
+    // wait states, was measured: 100 fewer s_nop per 27 rows, 136 instead of 128 VGPRs, pass B 0.344 instead
+    // of 0.332 ms behind pass A.)
     // after the block that starts at row yb: store the group's keys when it is complete
     auto flush = [&](int yb) {
         if constexpr (STORE)

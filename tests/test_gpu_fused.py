@@ -260,20 +260,26 @@ def test_general_shape_narrow_kernels(gpu_ctx, oracle):
 
 @pytest.mark.parametrize("w,h,b,D,win,sign", [
     (41, 30, 1, 128, 9, 1), (40, 64, 1, 100, 5, -1), (7, 12, 4, 65, 4, 1), (130, 35, 1, 96, 11, 1),
-    (33, 9, 1, 128, 3, -1),
+    (33, 9, 1, 128, 3, -1), (24, 131, 1, 128, 9, 1), (19, 200, 1, 66, 7, -1), (50, 65, 4, 127, 11, 1),
+    (30, 5, 1, 80, 5, 1), (30, 10, 1, 128, 9, 1), (12, 17, 1, 128, 11, -1), (9, 449, 1, 90, 3, 1),
+    (21, 33, 1, 128, 7, 1), (16, 97, 1, 70, 5, 1),
 ])
 def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
-    """65..128 levels (two levels per lane in pass B; config 5's per-GPU share is 128)."""
+    """65..128 levels (config 5's per-GPU share is 128): pass B with two levels per lane; heights around the
+    key groups of 63 rows and the LDS key buffer (buffered, one group, unbuffered), odd and even heights;
+    match_max 4 makes ties frequent, so the lowest-level rule decides."""
     left, right = synth.noise_pair(w, h, b, seed=77 + D)
     fr, fm = (0, 1) if sign > 0 else (1, 0)
     kw = dict(disp_max=D - 1, frame_ref=fr, frame_match=fm, match_fn=1, match_max=4, match_interval=1,
               aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
-    disp, best, _ = m.ComputeCorrespondence(left, right)
-    assert m.used_fused
-    assert np.array_equal(disp, odisp)
-    util.assert_bit_equal(best, obest, "best cost")
+    for keybuf in (-1, 0, 1):
+        with gpu_ctx.options(keybuf=keybuf):
+            m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+            disp, best, _ = m.ComputeCorrespondence(left, right)
+        assert m.used_fused
+        assert np.array_equal(disp, odisp), keybuf
+        util.assert_bit_equal(best, obest, "best cost (keybuf %d)" % keybuf)
 
 
 @pytest.mark.parametrize("w,h,b,D,win,sign,step,kw", [
