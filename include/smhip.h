@@ -125,6 +125,13 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
 int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
                      size_t row_elems, int x_width, int y_width, int average);
 
+/* The same with the reference's other border modes (EBorderMode, Image.h:98-104; borderIndex,
+ * BoxFilter.cpp:29-65): 1 replicate, 2 reflect, 3 cyclic, for the row pass (the source image's mode,
+ * BoxFilter.cpp:219) and the column pass (the destination's, :231).  0 (zero padding) is refused: the
+ * reference throws on it as soon as a window crosses the border.  The hot path only uses replicate. */
+int smhip_box_filter_border(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands, size_t row_elems,
+                            int window, int average, int border_x, int border_y);
+
 /* MinFilter<float> (MinFilter.h:31, MinFilter.cpp:122-209), replicate border, in place */
 int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int n_bands,
                      size_t row_elems, int x_width, int y_width);

@@ -143,6 +143,9 @@ def lib():
         L.smo_match_quality.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_long, C.c_int,
                                         C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp]
         L.smo_match_quality.restype = None
+        L.smo_box_filter_border.argtypes = [fp, fp, C.c_int, C.c_int, C.c_int, C.c_long, C.c_int, C.c_int,
+                                            C.c_int, C.c_int]
+        L.smo_box_filter_border.restype = None
         for name in ("smo_subpixel_fit", "smo_collapse", "smo_refine", "smo_preprocess_blur"):
             getattr(L, name).restype = None
         for name in ("smo_raw_costs", "smo_box_filter", "smo_min_filter", "smo_convolve_14641",
@@ -297,6 +300,14 @@ def refine(cost, mind, disp, step, disp_min, mode):
     lib().smo_refine(_fp(c), _fp(m) if m is not None else None, _i32(dd), w, h, d, w * d, step,
                      disp_min, mode, _fp(out))
     return out
+
+
+def box_filter_border(cost, window, border_x, border_y, average=True):
+    c = np.array(cost, dtype=np.float32, order="C", copy=True)
+    h, w, d = c.shape
+    tmp = np.empty_like(c)
+    lib().smo_box_filter_border(_fp(c), _fp(tmp), w, h, d, w * d, window, 1 if average else 0, border_x, border_y)
+    return c
 
 
 def match_quality(cost, cert, fdisp, disp_min, step_inv, quality_mode, use_fit, norm_bands, take_sqrt):

@@ -257,6 +257,50 @@ static void box_lines(const float *src, float *dst, long n_sums, int len, long s
     }
 }
 
+/* borderIndex, BoxFilter.cpp:29-65 (1 replicate, 2 reflect, 3 cyclic) */
+static int border_index(int i, int len, int mode)
+{
+    if (i < 0)
+        return mode == 2 ? -i : (mode == 3 ? i + len : 0);
+    if (i >= len)
+        return mode == 2 ? len + len - i - 2 : (mode == 3 ? i - len : len - 1);
+    return i;
+}
+
+/* boxFilterLines with a border mode (BoxFilter.cpp:70-168): first sum :92-107, left border :117-130,
+ * centre :133-147, right border :150-166 -- one formula with borderIndex applied on both sides */
+static void box_lines_border(const float *src, float *dst, long n_sums, int len, long stride, int w,
+                             int average, int mode)
+{
+    int pr = w / 2, pl = pr - w;
+    float scale = (float)(average ? 1.0 / w : 1);
+    for (long k = 0; k < n_sums; k++) {
+        float acc = 0;
+        for (int i = pl + 1; i <= pr; i++)
+            acc += scale * src[k + stride * border_index(i, len, mode)];
+        dst[k] = acc;
+    }
+    for (int x = 1; x < len; x++) {
+        const float *lft = src + stride * border_index(x + pl, len, mode);
+        const float *rgt = src + stride * border_index(x + pr, len, mode);
+        const float *prev = dst + stride * (x - 1);
+        float *cur = dst + stride * x;
+        for (long k = 0; k < n_sums; k++)
+            cur[k] = prev[k] + scale * (-lft[k] + rgt[k]);
+    }
+}
+
+/* BoxFilter (BoxFilter.cpp:175-239) with src.borderMode for the rows (:219) and dst.borderMode for the
+ * columns (:231) */
+void smo_box_filter_border(float *cost, float *tmp, int w, int h, int nb, long row_elems, int window,
+                           int average, int border_x, int border_y)
+{
+    for (int y = 0; y < h; y++)
+        box_lines_border(cost + (size_t)y * row_elems, tmp + (size_t)y * row_elems, nb, w, nb, window,
+                         average, border_x);
+    box_lines_border(tmp, cost, (long)nb * w, h, row_elems, window, average, border_y);
+}
+
 void smo_box_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,
                     int window, int average)
 {

@@ -70,6 +70,9 @@ void smo_raw_costs(const uint8_t *ref, const uint8_t *mtc, long img_row_bytes,
 /* BoxFilter.cpp:173-239 (CPU branch), :70-170; replicate border only */
 void smo_box_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,
                     int window, int average);
+/* the same with EBorderMode 1 replicate / 2 reflect / 3 cyclic per pass (BoxFilter.cpp:29-65) */
+void smo_box_filter_border(float *cost, float *tmp, int w, int h, int nb, long row_elems, int window,
+                           int average, int border_x, int border_y);
 
 /* MinFilter.cpp:122-202 (doMax = false); replicate border */
 void smo_min_filter(float *cost, float *tmp, int w, int h, int nb, long row_elems,

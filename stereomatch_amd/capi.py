@@ -22,7 +22,7 @@ SYMBOLS = [
     "smhip_convolve_14641", "smhip_convolve_14641_to",
     "smhip_diffusion_iter", "smhip_pad_costs", "smhip_wta", "smhip_fused_box_wta_keys",
     "smhip_keys_decode", "smhip_fused_box_wta", "smhip_profile_begin", "smhip_profile_end", "smhip_profile_get", "smhip_fused_box_wta_noalloc",
-    "smhip_subpixel_fit", "smhip_collapse", "smhip_refine", "smhip_match_quality",
+    "smhip_subpixel_fit", "smhip_collapse", "smhip_refine", "smhip_match_quality", "smhip_box_filter_border",
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
     "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run", "smhip_pad_wta_keys",
@@ -133,6 +133,7 @@ def load():
     L.smhip_subpixel_fit.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, sz, cf]
     L.smhip_collapse.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, ci, sz, cf, vp, vp]
     L.smhip_refine.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, vp]
+    L.smhip_box_filter_border.argtypes = [vp, vp, ci, ci, ci, sz, ci, ci, ci, ci]
     L.smhip_match_quality.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, sz, cf, cf, ci, ci, ci, ci, vp, vp]
     L.smhip_diffusion_run.argtypes = [vp, vp, vp, vp, ci, ci, ci, sz, cf, cf, ci, C.POINTER(ci)]
     L.smhip_convolve_14641_run.argtypes = [vp, vp, vp, ci, ci, ci, sz, ci, C.POINTER(ci)]
@@ -387,6 +388,10 @@ class Context:
     def refine(self, d_disp, d_cost, d_min, w, h, nb, row_elems, disp_step, disp_min, mode, d_fdisp):
         self._chk(self.L.smhip_refine(self.h, _ptr(d_disp), _ptr(d_cost), _ptr(d_min), w, h, nb,
                                       row_elems, disp_step, disp_min, mode, _ptr(d_fdisp)))
+
+    def box_filter_border(self, d_cost, w, h, nb, row_elems, window, average, border_x, border_y):
+        self._chk(self.L.smhip_box_filter_border(self.h, _ptr(d_cost), w, h, nb, row_elems, window, int(average),
+                                                 border_x, border_y))
 
     def match_quality(self, d_cost, d_cert, d_fdisp, w, h, nb, row_elems, cert_row_elems, disp_min,
                       disp_step_inv, quality_mode, use_fit, norm_bands, take_sqrt, d_fcost, d_fcert):

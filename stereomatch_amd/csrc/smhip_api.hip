@@ -550,6 +550,34 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     return SMHIP_OK;
 }
 
+int smhip_box_filter_border(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t row_elems, int window,
+                            int average, int border_x, int border_y)
+{
+    if (border_x == 1 && border_y == 1)
+        return smhip_box_filter(ctx, d_cost, w, h, nb, row_elems, window, window, average);
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_dsi(d_cost, w, h, nb, row_elems);
+    if (rc) return rc;
+    // eBorderZero: the reference only treats it in the first sum of a line and throws "bad borderMode" from
+    // borderIndex as soon as a window reaches over the border (BoxFilter.cpp:29-65, :117-124)
+    if (border_x < 1 || border_x > 3 || border_y < 1 || border_y > 3)
+        return fail(SMHIP_EINVAL, "BoxFilter: border modes are 1 (replicate), 2 (reflect), 3 (cyclic)");
+    if (window < 1 || window > w || window > h)
+        return fail(SMHIP_EINVAL, "BoxFilter: window %d too large for %dx%d (double wrapping)", window, w, h);
+    void *tmp = nullptr;
+    rc = ws_get(ctx, WS_TMP, row_elems * (size_t)h * sizeof(float), &tmp);
+    if (rc) return rc;
+    float scale = (float)(average ? 1.0 / window : 1);
+    long nh = (long)h * nb, nv = (long)w * nb;
+    smk::box_lines_border_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
+        d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, window, scale, border_x);
+    smk::box_lines_border_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
+        (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, window, scale, border_y);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
 // Rows per workgroup of the tile kernels: 128 for large volumes (6 % re-computed halo rows), down
 // to 16 for small ones so that a launch still has on the order of a thousand workgroups.
 static int tile_seglen(const smhip_ctx *ctx, int w, int h, int nb)

@@ -92,6 +92,40 @@ __global__ void raw_costs_kernel(RawArgs a, float *cost, size_t row_elems)
 // chain c -> (o = c / n_sums, k = c % n_sums) starts at o*outer_stride + k and steps by
 // `stride` elements.  Horizontal pass: n_sums = D, stride = D, outer = rows.  Vertical
 // pass: n_sums = W*D, stride = row_elems, one outer.
+// borderIndex, BoxFilter.cpp:29-65: 1 replicate, 2 reflect, 3 cyclic (no double wrapping: |overhang| < len)
+__device__ __forceinline__ int border_index(int i, int len, int mode)
+{
+    if (i < 0)
+        return mode == 2 ? -i : (mode == 3 ? i + len : 0);
+    if (i >= len)
+        return mode == 2 ? len + len - i - 2 : (mode == 3 ? i - len : len - 1);
+    return i;
+}
+
+// the same running sums with the reference's other border modes (smhip_box_filter_border); not a hot path
+__global__ void box_lines_border_kernel(const float *src, float *dst, long n_chains, int n_sums,
+                                        size_t outer_stride, size_t stride, int len, int w, float scale, int mode)
+{
+    long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_chains)
+        return;
+    long o = c / n_sums;
+    size_t base = (size_t)o * outer_stride + (size_t)(c - o * n_sums);
+    const float *s = src + base;
+    float *t = dst + base;
+    int pr = w / 2, pl = pr - w;
+    float acc = 0;
+    for (int i = pl + 1; i <= pr; i++)
+        acc += scale * s[stride * border_index(i, len, mode)];
+    t[0] = acc;
+    for (int x = 1; x < len; x++) {
+        float lft = s[stride * border_index(x + pl, len, mode)];
+        float rgt = s[stride * border_index(x + pr, len, mode)];
+        acc = acc + scale * (-lft + rgt);
+        t[stride * x] = acc;
+    }
+}
+
 __global__ void box_lines_kernel(const float *src, float *dst, long n_chains, int n_sums,
                                  size_t outer_stride, size_t stride, int len, int w, float scale)
 {

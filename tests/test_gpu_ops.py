@@ -427,6 +427,22 @@ def test_opt_so(gpu_ctx, oracle, h, w, d, b, smooth):
     assert np.array_equal(gb, np.take_along_axis(c, want[..., None], axis=2)[..., 0])
 
 
+@pytest.mark.parametrize("h,w,d,win", [(12, 17, 5, 5), (9, 9, 16, 9), (20, 31, 7, 4), (6, 40, 33, 3)])
+@pytest.mark.parametrize("bx,by", [(2, 2), (3, 3), (2, 1), (1, 3), (1, 1)])
+def test_box_filter_border_modes(gpu_ctx, oracle, h, w, d, win, bx, by):
+    """smhip_box_filter_border: the reference's reflect / cyclic border modes (BoxFilter.cpp:29-65), per pass,
+    against the oracle's restatement (parity unpinned: the hot path, and every reference output, uses
+    replicate); zero padding is refused as the reference refuses it."""
+    c = util.rand_dsi(h, w, d, 900 + w, "float")
+    for average in (True, False):
+        got = run_inplace(gpu_ctx, c, lambda b, W, H, D, re: gpu_ctx.box_filter_border(b, W, H, D, re, win, average, bx, by))
+        util.assert_bit_equal(got, oracle.box_filter_border(c, win, bx, by, average), "box %d/%d" % (bx, by))
+    if (bx, by) == (1, 1):
+        util.assert_bit_equal(got, oracle.box_filter(c, win, False), "replicate = smhip_box_filter")
+    with pytest.raises(capi.SmhipError, match="border modes"):
+        gpu_ctx.box_filter_border(up(gpu_ctx, c), w, h, d, w * d, win, 1, 0, 1)
+
+
 # AggrBayesian is the one operator in TOLERANCE MODE: exp / log come from the device's math
 # library, about 1 ulp from the host libm the oracle (and the reference) calls, and an energy is
 # -log of a sum of such values.  Stated tolerance: |E_gpu - E_oracle| <= BAYES_RTOL * max(1, |E|)
