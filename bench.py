@@ -58,6 +58,8 @@ def main():
                          "through pinned host memory)")
     ap.add_argument("--single-device", action="store_true",
                     help="rehearsal: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--one-rank-rehearsal", action="store_true",
+                    help="run the N > 1 code path in a process group of one rank (no scaling figure)")
     ap.add_argument("--check-oracle", action="store_true",
                     help="rehearsal / test: rank 0 compares EVERY decoded frame with the CPU oracle")
     ap.add_argument("--max-call-levels", type=int, default=MAX_CALL_LEVELS,
@@ -81,15 +83,23 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if args.single_device:
         local_rank = 0
+    # --one-rank-rehearsal: the N > 1 code path (process group, config 5 in slabs and calls, key pipeline with a
+    # real collective, timing all-gather) in a group of ONE rank -- what a one-GPU box can run of it over RCCL
+    multi = world > 1 or args.one_rank_rehearsal
+    if args.one_rank_rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if multi:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
 
-    sharded = world > 1 and not args.weak          # config 5, strong scaling
+    sharded = multi and not args.weak          # config 5, strong scaling
     max_call = args.max_call_levels
     b, win = args.bands, args.window
     W = args.width or (7680 if sharded else 1920)
@@ -112,7 +122,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     extra = None
-    if world == 1 and not args.no_extra and rank == 0:
+    if not multi and not args.no_extra and rank == 0:
         # the side measurements (configs 4 and 5 per GPU) run first: they also bring the device out of
         # its idle power state before the W warm-up steps
         extra = extra_configs(np, capi, synth, ctx)
@@ -120,12 +130,12 @@ def main():
     t_ref = torch.from_numpy(left.reshape(H, W * b)).to(dev)
     t_mtc = torch.from_numpy(right.reshape(H, W * b)).to(dev)
     keys = torch.empty((W, H), dtype=torch.int64, device=dev)   # column-major key image
-    keys2 = torch.empty_like(keys) if world > 1 else None
-    keys_part = torch.empty_like(keys) if Dg > max_call and world > 1 else None
+    keys2 = torch.empty_like(keys) if multi else None
+    keys_part = torch.empty_like(keys) if Dg > max_call and multi else None
     disp = torch.empty((H, W), dtype=torch.int32, device=dev)
     best = torch.empty((H, W), dtype=torch.float32, device=dev)
     p = capi.match_params(W, H, b, D, match_fn=1, match_interval=1, match_max=1000)
-    calls_per_step = 1 if world == 1 else (Dg + max_call - 1) // max_call
+    calls_per_step = 1 if not multi else (Dg + max_call - 1) // max_call
 
     want = None
     if args.check_oracle and rank == 0:
@@ -134,7 +144,7 @@ def main():
     produce_events = []
 
     def produce(buf, _frame):
-        if world == 1:
+        if not multi:
             ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, d_first, Dg, buf.data_ptr())
             return
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,8 +168,8 @@ def main():
             frames_checked[0] += 1
 
     # N > 1: the one exchange step (int64 MIN all-reduce over xGMI) overlaps the next frame
-    pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume,
-                                      host_staging=(args.backend != "nccl")) if world > 1 else None
+    pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume, force_collective=(world == 1),
+                                      host_staging=(args.backend != "nccl")) if multi else None
 
     trace = bool(os.environ.get("BENCH_TRACE"))
 
@@ -178,7 +188,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1 and not args.check_oracle:
+    if not multi and not args.check_oracle:
         # clock ramp: a cold GPU runs the first ~100 ms of launches below its sustained clocks (pass B 0.358
         # instead of 0.3375 ms), and W warm-up steps of 0.73 ms do not get it there; untimed, like the warm-up
         t_ramp = time.perf_counter()
@@ -203,9 +213,9 @@ def main():
     compute_ms = (sum(e0.elapsed_time(e1) for e0, e1 in produce_events) / len(produce_events) if produce_events
                   else (ms_a + ms_b) / max(1, n_prof))
 
-    t = torch.tensor([dt, compute_ms], dtype=torch.float64, device="cpu" if args.backend != "nccl" and world > 1 else dev)
+    t = torch.tensor([dt, compute_ms], dtype=torch.float64, device="cpu" if args.backend != "nccl" and multi else dev)
     per_rank_compute = [compute_ms]
-    if world > 1:
+    if multi:
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         dt = max(float(g[0]) for g in gathered)
@@ -226,7 +236,7 @@ def main():
         bytes_fused = 8.0 * n_call + 2.0 * b * W * H + 8.0 * W * H
         ta, tb = ms_a / n_prof * 1e-3, ms_b / n_prof * 1e-3
         traffic, traffic_source = {}, None
-        config3 = world == 1 and (W, H, Dg, b, win) == (1920, 1080, 256, 1, 9)
+        config3 = not multi and (W, H, Dg, b, win) == (1920, 1080, 256, 1, 9)
         if config3 and os.path.exists(args.traffic_json):    # counters were collected on config 3 only
             with open(args.traffic_json) as f:
                 traffic = json.load(f)
@@ -262,7 +272,7 @@ def main():
             workload = "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, D=%d (%d levels per GPU%s)" % (
                 win, win, W, H, b, D, Dg,
                 ", int64-MIN %s all-reduce of keys" % ("RCCL" if args.backend == "nccl" else args.backend)
-                if world > 1 else "")
+                if multi else "")
         out = {
             "metric": "cost-volume throughput (G pixel*disparity/s)",
             "value": round(value, 2), "unit": "G pixel*disparity/s",
@@ -275,14 +285,14 @@ def main():
                 "width": W, "height": H, "bands": b, "disp_total": D, "disp_per_gpu": Dg,
                 "window": win, "match_fn": "AD", "match_interval": 1, "match_max": 1000,
                 "parallelism": "disparity slabs x%d" % world,
-                "collective_backend": (args.backend if world > 1 else None)},
+                "collective_backend": (args.backend if multi else None)},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernel": dominant["kernel"],
             "traffic_source": traffic_source,
             "roofline_fused": fused,
             "kernels": [ka, kb],
         }
-        if world > 1:
+        if multi:
             out["per_rank_compute_ms"] = per_rank_compute
             out["exposed_collective_ms"] = round(ms_step - max(per_rank_compute), 4)
             out["collective_bytes_per_step"] = W * H * 8
@@ -290,7 +300,7 @@ def main():
             out["frames_checked_vs_oracle"] = frames_checked[0]
         if extra is not None:
             out["extra"] = extra
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             got = (disp.cpu().numpy(), best.cpu().numpy())         # the frame the timed loop left behind
             out["cpu_baseline"], ok = cpu_baseline(np, left, right, args, Dg, win, got=got)
             out["verified_vs_oracle"] = ok
@@ -299,7 +309,7 @@ def main():
                 out["extra"]["config4_cpu"] = cpu_config4(np, synth)
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
