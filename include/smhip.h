@@ -78,6 +78,7 @@ enum smhip_option {
     SMHIP_OPT_MAXK,           /* iterations per pass of the multi-iteration filters, 1..4 */
     SMHIP_OPT_FLOAT_A,        /* 0: pass A by the integer kernels also where the float-lane kernel applies */
     SMHIP_OPT_KEYBUF,         /* key groups (of ~64 rows) pass B collects in LDS before it stores them; 0: none */
+    SMHIP_OPT_STORE_POLICY,   /* cache policy of the float-lane pass A's slab stores: 0 plain, 16 sc1, 18 sc1 + nt */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);

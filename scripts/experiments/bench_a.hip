@@ -188,6 +188,12 @@ static int run(int W, int H, int D, int d_first, int cutoff_in, bool check, int 
             smk::fused_rawbox_h_f_kernel<9, false, false, DS, 2, 2, 0><<<g, 128, (size_t)nmatch * 8 + nref * 4>>>(fa, T1, tyshift, Dp, scale, 0, cb, nref, nmatch, CH / 64); };
         if (cutoff_in >= 255) report("float lanes 2x2 + lean pass B", time_pair(f, [&] { passBf(T1); }), 0.f);
     }
+    CAND_F(2, 2, 16, "float lanes 2x2, stores sc0");
+    CAND_F(2, 2, 32, "float lanes 2x2, stores nt");
+    CAND_F(2, 2, 48, "float lanes 2x2, stores sc0 nt");
+    CAND_F(2, 2, 256, "float lanes 2x2, stores sc1");
+    CAND_F(2, 2, 288, "float lanes 2x2, stores sc1 nt");
+    CAND_F(2, 2, 304, "float lanes 2x2, stores sc1 sc0 nt");
     CAND_FK(2, 2, 0, 1, "float lanes 2x2, keep all");
     CAND_F(2, 2, 1, "float lanes 2x2, no stores");
     CAND_F(2, 2, 2, "float lanes 2x2, no loads");

@@ -1400,7 +1400,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         // (smhip_fused_f.h, a translation unit of its own); everything else: the integer kernels below
         const bool float_a = !chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0 &&
             smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, CH / 64,
-                                         a.sd != 0, nbands * (a.sd ? 255 * 255 : 255), ctx->stream);
+                                         a.sd != 0, nbands * (a.sd ? 255 * 255 : 255), ctx->stream,
+                                               ctx->opt[SMHIP_OPT_STORE_POLICY]);
 #define LAUNCH_A3(WIN, SD, NB)                                                                           \
         do {                                                                                             \
             if (chunked) smk::fused_rawbox_h_chunk_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>(   \

@@ -42,7 +42,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // glev = levels per lane of the pass B that follows (1, 2 or 4): the granule of the store predicate.
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 
-template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0>   // ABL: ablations of scripts/bench_a.hip
+template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))   // two waves per SIMD exist at most
 void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
@@ -181,11 +181,11 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     unsigned tb = 0;                                   // byte offset of the current block's first step
     auto put = [&](int voff, unsigned off, const float (&acc)[LPL]) {
         if constexpr (LPL == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[0]), trs, voff, off, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[0]), trs, voff, off, POL | (ABL >> 4));
         } else {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v = {__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1])};
-            __builtin_amdgcn_raw_buffer_store_b64(v, trs, voff, off, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(v, trs, voff, off, POL | (ABL >> 4));
         }
     };
     // does one level of the lane's group of glev levels (one lane of pass B, glev a multiple of LPL)

@@ -7,9 +7,9 @@ namespace smk {
 
 namespace {
 
-template <int WIN, bool SD, bool CUT, int DS>
-void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                  hipStream_t stream)
+template <int WIN, bool SD, bool CUT, int DS, int POL>
+void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
+                      hipStream_t stream)
 {
     // 256-level chunks: two waves of two levels per lane; a 128-level slab: one wave
     const int nw = Dp % 256 == 0 ? 2 : 1;
@@ -20,21 +20,43 @@ void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, i
     const size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
     dim3 grid(a.H, Dp / cw);
     if (nw == 2)
-        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2><<<grid, 128, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
+        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2, 0, POL><<<grid, 128, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
                                                                                    cb, nref, nmatch, glev);
     else
-        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 1><<<grid, 64, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
+        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 1, 0, POL><<<grid, 64, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
                                                                                   cb, nref, nmatch, glev);
+}
+
+// Cache policy of the slab stores (aux bits of buffer_store on gfx950: 2 = nt, 16 = sc1).  Measured in the
+// pipeline (scripts/exp_store_policy.sh, pass A / pass B ms): config 3 plain 0.387 / 0.331, sc1 0.380 / 0.331,
+// nt 0.410 / 0.315, sc1 + nt 0.396 / 0.316 (step 0.728 / 0.721 / 0.735 / 0.722); 3840x2160x256 step 3.12 plain,
+// 3.08 sc1, 2.97 sc1 + nt; 7680x4320x256 11.99 / 11.84 / 11.59; 7680x4320x128 6.81 / 6.69 / 6.52.  nt stores
+// leave no dirty lines in the L2 for pass B's first reads to wait behind, sc1 makes pass A itself faster; on
+// slabs of a few GB the two effects cancel, on larger ones sc1 + nt wins.  policy < 0: the library's choice
+// (sc1 below 4 GiB of slab, sc1 + nt from there on); 0 / 16 / 18 through SMHIP_OPT_STORE_POLICY.  (The integer
+// kernels keep plain stores: non-temporal ones made the 4-band pass A 6 % slower for a 3 % faster pass B.)
+template <int WIN, bool SD, bool CUT, int DS>
+void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
+                  hipStream_t stream, int policy)
+{
+    if (policy < 0)
+        policy = (size_t)a.W * a.H * Dp * sizeof(float) < ((size_t)4 << 30) ? 16 : 18;
+    if (policy == 0)
+        launch_shape_pol<WIN, SD, CUT, DS, 0>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
+    else if (policy == 16)
+        launch_shape_pol<WIN, SD, CUT, DS, 16>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
+    else
+        launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
 }
 
 template <int WIN>
 void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
-                   bool cut, hipStream_t stream)
+                   bool cut, hipStream_t stream, int policy)
 {
 #define SMK_F(SD, CUT)                                                                             \
     do {                                                                                           \
-        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream); \
-        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream);      \
+        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy); \
+        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy); \
     } while (0)
     if (sd) { if (cut) SMK_F(true, true); else SMK_F(true, false); }
     else    { if (cut) SMK_F(false, true); else SMK_F(false, false); }
@@ -44,7 +66,7 @@ void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, 
 }  // namespace
 
 bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
-                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream)
+                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy)
 {
     if (n_bands != 1 || (a.dstep != 1 && a.dstep != -1) || a.rn != a.rx || Dp % 128 != 0)
         return false;
@@ -56,10 +78,10 @@ bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift
         return false;
     const bool cut = a.cutoff < max_cost;                  // truncation can bite
     switch (window) {
-    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
-    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
-    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
-    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream); break;
+    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
+    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
+    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
+    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
     default: return false;
     }
     return true;

@@ -119,8 +119,8 @@ def test_config3_full_size_vs_oracle(gpu_ctx, oracle, pair, kw):
         odisp, obest, odepth, _ = oracle_run(O, left, right, disp_max=D - 1, aggr_window_size=9, **kw)
     finally:
         O.use_openmp(False)
-    for float_a in (1, 0):                       # the float-lane pass A and the integer kernels
-        with gpu_ctx.options(float_a=float_a):
+    for float_a, pol in ((1, -1), (1, 0), (1, 18), (0, -1)):   # float-lane pass A (store policies), integer kernels
+        with gpu_ctx.options(float_a=float_a, store_policy=pol):
             m = matcher.StereoMatcher(ctx=gpu_ctx, disp_max=D - 1, aggr_window_size=9, **kw)
             disp, best, depth = m.ComputeCorrespondence(left, right)
         assert m.used_fused
