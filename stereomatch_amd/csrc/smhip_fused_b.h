@@ -160,8 +160,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                 acc[i] = acc[i] + scale * (-od[i] + nw[i]);
                 if constexpr (VPL == 1) o = acc[0]; else o[i] = acc[i];
             }
-            if (need && y < H)
-                *(typename vecf<VPL>::type *)(sout + (size_t)y * s_row_elems) = o;
+            if (need && y < H)                           // (non-temporal: the DSI is read by another kernel, later)
+                __builtin_nontemporal_store(o, (typename vecf<VPL>::type *)(sout + (size_t)y * s_row_elems));
             return;
         }
         int s, bi;

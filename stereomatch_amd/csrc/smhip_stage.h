@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void raw_costs_rows_kernel(FusedA a, float *__
             v[j] = out ? outside : (float)e;
         }
         typename fvec<4>::type o = {v[0], v[1], v[2], v[3]};
-        vstore<4>(row + ((size_t)x * D4 + k4) * 4, o);
+        vstore_plain<4>(row + ((size_t)x * D4 + k4) * 4, o);
         x += dx;
         k4 += dk;
         if (k4 >= D4) {
