@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     // The kernel is bound by instruction issue as much as by HBM (VALU + SALU + s_nop slots per row against
     // the bytes of a row), so the per-row instruction count matters: the row offset is one 32 x 32 -> 64 bit
     // product, PadCosts and the end of the slab are one select per level, the key select takes its scalars
-    // without a copy.  The branch around the load stays: a form without it (idle lanes read one shared
+    // without a copy.  (The loads are non-temporal; with the sc0 / sc1 bits added -- buffer loads -- the time is
+    // the same, without nt pass B takes 0.383 instead of 0.334 ms.)  The branch around the load stays: a form without it (idle lanes read one shared
     // element) is 4 % faster when pass B runs alone (scripts/bench_b.hip) and 7 % slower behind pass A.
     const unsigned band_elems = ((unsigned)W << tyshift) * (unsigned)Dp;     // (< 2^32: the launch sees to it)
     const int tymask = (1 << tyshift) - 1;
