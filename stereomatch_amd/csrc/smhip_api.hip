@@ -1336,10 +1336,21 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     int tyshift = tuned_a ? 5 : 0;
     if (tuned_a && ctx->opt[SMHIP_OPT_TYSHIFT] >= 0)
         tyshift = ctx->opt[SMHIP_OPT_TYSHIFT];           // (smhip_set_option keeps it within 0..8)
-    while (tyshift > 0 && ((((unsigned long long)W << tyshift) * (unsigned long long)Dp) >> 32) != 0)
+    // 128-level slabs (every GPU's share of config 5 at N = 8): columns in pairs, so that pass B reads a row of
+    // two columns with one 1-KiB wave load (smhip_fused_b.h, PAIR).  Only with the float-lane pass A, which
+    // writes that layout, and from 3584 columns on: a wave per pair halves the waves, and below about 1800 of
+    // them the walk is bound by the latency of a wave's own row loop (3840 wide: pass B 0.79 -> 0.69 ms, 7680:
+    // 3.22 -> 2.84; 3072: 0.49 -> 0.51, 1920: 0.25 -> 0.27).  SMHIP_OPT_PAIRED = 0 switches it off, 1 forces it
+    // at any width (tests).
+    bool paired = tuned_a && !keep_all && Dp == 128 && p->n_bands == 1 && ctx->opt[SMHIP_OPT_PAIRED] != 0 &&
+                  (W >= 3584 || ctx->opt[SMHIP_OPT_PAIRED] > 0) &&
+                  ctx->opt[SMHIP_OPT_CHUNK] < 0 && ctx->opt[SMHIP_OPT_FLOAT_A] != 0 &&
+                  (window == 5 || window == 7 || window == 9 || window == 11);
+    const size_t Wc = paired ? ((size_t)W + 1) / 2 : (size_t)W, DpL = paired ? 256 : (size_t)Dp;
+    while (tyshift > 0 && ((((unsigned long long)Wc << tyshift) * (unsigned long long)DpL) >> 32) != 0)
         tyshift--;                                      // pass B multiplies the band size as a 32-bit number
     size_t bands = ((size_t)H + (1u << tyshift) - 1) >> tyshift;
-    size_t trow = (size_t)W * Dp;                       // floats per image row of T
+    size_t trow = Wc * DpL;                             // floats per image row of T
     size_t t_elems = (bands << tyshift) * trow;
 
     // pass A stages whole rows in LDS; rows above 40 KB (4 bands: wider than 2560 pixels) are staged
@@ -1398,10 +1409,19 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
                         window, adstep);
         // one band, unit step, point reference interval, window 5..11: the float-lane kernel
         // (smhip_fused_f.h, a translation unit of its own); everything else: the integer kernels below
-        const bool float_a = !chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0 &&
-            smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, CH / 64,
-                                         a.sd != 0, nbands * (a.sd ? 255 * 255 : 255), ctx->stream,
-                                               ctx->opt[SMHIP_OPT_STORE_POLICY]);
+        bool float_a = false;
+        if (!chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0) {
+            const int max_cost = nbands * (a.sd ? 255 * 255 : 255), pol = ctx->opt[SMHIP_OPT_STORE_POLICY];
+            const long a_lds_min = ctx->opt[SMHIP_OPT_A_LDS_KB] < 0 ? -1 : (long)ctx->opt[SMHIP_OPT_A_LDS_KB] * 1024;
+            if (paired)
+                paired = smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, 4,
+                                                      a.sd != 0, max_cost, ctx->stream, pol, true, a_lds_min);
+            float_a = paired || smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale,
+                                                             keep_all, CH / 64, a.sd != 0, max_cost, ctx->stream,
+                                                             pol, false, a_lds_min);
+        } else {
+            paired = false;
+        }
 #define LAUNCH_A3(WIN, SD, NB)                                                                           \
         do {                                                                                             \
             if (chunked) smk::fused_rawbox_h_chunk_kernel<WIN, SD, NB><<<ga, tpa, lds, ctx->stream>>>(   \
@@ -1437,18 +1457,34 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 
     if (wide) {
         // one wave per pixel column and chunk, 4 columns per block, columns dealt per XCD
-        const int wpb = 4;
+        // Resident pass B waves per CU, bounded through the LDS a workgroup asks for (160 KB per CU).  Every wave
+        // walks a whole column, so the grid runs in rounds; with b workgroups per XCD (32 CUs), two workgroups
+        // per CU (rounds of 64) beat the four that the key buffer alone allows whenever the last round of 64 is
+        // at least 0.6 full -- b = 104 .. 120: 14-19 % faster (3840x2160x256 1.50 -> 1.29 ms, 0.82 of 8 TB/s),
+        // 176 .. 240: 2-5 % -- and lose otherwise (b = 80: 20 % slower, 96: 9 %, 136: 11 %, 160: 4 %): measured,
+        // scripts/exp_occupancy*.sh, profiles/r02_occupancy.log.  SMHIP_OPT_B_WAVES: 0 no bound, n waves per CU.
+        const int wpb_policy = 4;
         int x_per_xcd = (W + 7) / 8;
-        dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), keep_all ? (Dp + 255) / 256 : n_chunks);
+        const int b_chunks = keep_all ? (Dp + 255) / 256 : n_chunks;
+        int b_waves = ctx->opt[SMHIP_OPT_B_WAVES] > 0 ? (ctx->opt[SMHIP_OPT_B_WAVES] + 1) & ~1 : 0;
+        const bool b_policy = ctx->opt[SMHIP_OPT_B_WAVES] < 0;
+        auto two_per_cu = [](long b) { return b > 64 && (b % 64 == 0 || b % 64 >= 38); };
+        if (b_policy && !keep_all && CH == 256 && two_per_cu((long)((x_per_xcd + wpb_policy - 1) / wpb_policy) * b_chunks))
+            b_waves = 8;
+        const int wpb = (b_waves % 4) ? 2 : 4;
+        dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), b_chunks);
         // keys collect in a wave-private LDS buffer of kb_rows rows (a multiple of the kernel's key group)
         // and go to memory in long runs: stores into the read stream cost HBM bus turn-arounds
         const int kblk = (window == 3 || window == 5 || window == 7 || window == 9 || window == 11) ? window : 8;
         const int kgrp = (64 / kblk) * kblk;
-        int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : 18;   // 0: unbuffered
+        // (two workgroups per CU leave each 80 KB: 36 groups, 8K x 256 5.54 -> 5.42 ms)
+        int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (b_policy && b_waves == 8 ? 36 : 18);   // 0: unbuffered
         if (kb_groups > (H + kgrp - 1) / kgrp) kb_groups = (H + kgrp - 1) / kgrp;
         if (kb_groups > 64) kb_groups = 64;                 // 4 waves x 64 groups x 64 rows x 8 B = 128 KB
         const int kb_rows = kgrp * kb_groups;
-        const size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long);
+        size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long);
+        const size_t b_lds_min = b_waves ? (size_t)(163840 / (b_waves / wpb)) & ~(size_t)255 : 0;   // 160 KB of LDS per CU
+        if (kb_lds < b_lds_min) kb_lds = b_lds_min;
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
         d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
@@ -1458,7 +1494,27 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         case 2: LAUNCH_BT(WIN, 2); break;              \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
-        if (!keep_all) {
+        if (paired) {                // (the float-lane pass A ran: window 5 .. 11, Dp 128, keys out)
+            const int xp = (((W + 1) / 2) + 7) / 8;     // column pairs per XCD
+            dim3 gp(8 * ((xp + wpb - 1) / wpb), 1);
+            const int pgrp = (32 / window) * window;    // rows per key group of a half-wave
+            int pg = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (1134 + pgrp - 1) / pgrp;   // runs of ~9 KB per column, as above
+            if (pg > (H + pgrp - 1) / pgrp) pg = (H + pgrp - 1) / pgrp;
+            if (pg > 64) pg = 64;                       // 4 waves x 2 columns x 64 groups x 32 rows x 8 B = 128 KB
+            const int prow = pgrp * pg;
+            size_t plds = (size_t)wpb * 2 * prow * sizeof(long long);
+            if (plds < b_lds_min) plds = b_lds_min;
+#define LAUNCH_BP(WIN) smk::fused_boxv_wta_vpl_kernel<WIN, 4, 0, false, true><<<gp, 64 * wpb, plds, ctx->stream>>>( \
+        (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,                      \
+        d_first, xp, kout, n_pix, nullptr, 0, prow)
+            switch (window) {
+            case 5: LAUNCH_BP(5); break;
+            case 7: LAUNCH_BP(7); break;
+            case 9: LAUNCH_BP(9); break;
+            default: LAUNCH_BP(11); break;
+            }
+#undef LAUNCH_BP
+        } else if (!keep_all) {
             switch (window) {        // static windows: the leaving row comes from registers
             case 3: LAUNCH_BW(3) break;
             case 5: LAUNCH_BW(5) break;

@@ -45,33 +45,46 @@ __device__ __forceinline__ void load_row(const float *p, float (&v)[VPL])
 // the DSI S[y][x][D] (reference layout, row stride s_row_elems; D % VPL == 0): RawCosts + one
 // AggrBox with 12 bytes per voxel instead of 20.  All levels are kept (the min filter that may
 // follow reads the aggregated costs of padded positions too, StcAggregate.cpp:351-365).
-template <int WIN, int VPL, int ABL = 0, bool STORE = false>   // ABL: ablation switches of scripts/bench_b.hip (0 = product)
+// PAIR = true (VPL 4, 128-level slabs in the paired layout T[band][x / 2][ty][x & 1][128] that
+// the float-lane pass A writes, smhip_fused_f.h PAIRED): a wave owns TWO pixel
+// columns, 2c in lanes 0..31 and 2c + 1 in lanes 32..63, four levels per lane.  In that layout the 128 levels
+// of the two columns are adjacent, so a row of the pair is one 1-KiB wave load as for a 256-level column (the
+// unpaired 128-level slab is read with 512-byte loads, whose ceiling is 0.68 instead of 0.86 of 8 TB/s,
+// scripts/membw8.hip), the two columns are independent (no exchange between the half-waves), and one DPP
+// reduction over each half-wave serves two pixels.  W, H stay the image's; Dp must be 128.
+template <int WIN, int VPL, int ABL = 0, bool STORE = false, bool PAIR = false>   // ABL: ablation switches of scripts/bench_b.hip (0 = product)
 __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
     long long *__restrict__ keys, size_t keys_chunk_stride, float *__restrict__ S = nullptr,
-    size_t s_row_elems = 0, int kb_rows = 0)          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8
+    size_t s_row_elems = 0, int kb_rows = 0)          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8 (PAIR: * 16)
 {
+    static_assert(!PAIR || (VPL == 4 && !STORE), "paired columns: four levels per lane, keys out");
     extern __shared__ __attribute__((aligned(16))) long long kbuf_all[];
     constexpr int BLK = WIN ? WIN : 8;
-    constexpr int GRP = (64 / BLK) * BLK;              // rows per key store (63 for WIN 9)
+    constexpr int KLANES = PAIR ? 32 : 64;             // lanes that keep the keys of one pixel column
+    constexpr int GRP = (KLANES / BLK) * BLK;          // rows per key store (63 for WIN 9; PAIR: 27)
     constexpr int CH = 64 * VPL;
     const int lane = threadIdx.x & 63;
+    const int klane = PAIR ? (lane & 31) : lane;
     // XCD-aware column order: workgroups are dealt round-robin to the 8 XCDs, so give each
-    // XCD a contiguous range of columns.  Correctness does not depend on placement.
+    // XCD a contiguous range of columns (PAIR: of column pairs).  Correctness does not depend on placement.
     const int wpb = blockDim.x >> 6;
     const int blk = blockIdx.x, wib = threadIdx.x >> 6;
     const int xin = (blk >> 3) * wpb + wib;
-    const int x = (blk & 7) * x_per_xcd + xin;
+    const int xc = (blk & 7) * x_per_xcd + xin;        // column, or column pair
     const int chunk = blockIdx.y;
-    if (x >= W || xin >= x_per_xcd)
+    if (xc >= (PAIR ? (W + 1) / 2 : W) || xin >= x_per_xcd)
         return;                                        // whole wave exits together
-    const int k0 = chunk * CH + lane * VPL;            // first level of this lane (k0 + VPL <= Dp)
-    const size_t j = ((size_t)x << tyshift) * Dp + k0;
+    const int x = PAIR ? 2 * xc + (lane >> 5) : xc;
+    const int DpL = PAIR ? 256 : Dp;                   // floats per slab row of this wave's column (pair)
+    const int Wc = PAIR ? (W + 1) / 2 : W;
+    const int k0 = PAIR ? (lane & 31) * 4 : chunk * CH + lane * VPL;   // first level of this lane (k0 + VPL <= Dp)
+    const size_t j = PAIR ? ((size_t)xc << tyshift) * 256 + lane * 4 : ((size_t)x << tyshift) * Dp + k0;
     const int w = WIN ? WIN : win;
     const int pr = w / 2, pl = pr - w;
-    long long *kout = keys + (size_t)chunk * keys_chunk_stride + (size_t)x * H;
-    long long *kbuf = kbuf_all + (size_t)wib * kb_rows;
+    long long *kout = keys + (size_t)chunk * keys_chunk_stride + (size_t)min(x, W - 1) * H;
+    long long *kbuf = kbuf_all + (size_t)wib * kb_rows * (PAIR ? 2 : 1) + (PAIR ? (size_t)(lane >> 5) * kb_rows : 0);
     int kb_first = 0;                                  // first row held in the LDS key buffer
 
     bool padded[VPL], live[VPL], repl[VPL];
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
 #pragma unroll
     for (int i = 0; i < VPL; i++) {
         int k = k0 + i;
-        live[i] = k < D;
+        live[i] = k < D && x < W;                      // (PAIR: the odd column of the last pair may not exist)
         int xm = x + disp0 + (k < D ? k : D - 1) * dstep;
         padded[i] = (xm < 0) || (xm >= W);             // PadLine, StcRawCosts.cpp:451-456
         repl[i] = padded[i] || !live[i];
@@ -100,12 +113,12 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     // without a copy.  (The loads are non-temporal; with the sc0 / sc1 bits added -- buffer loads -- the time is
     // the same, without nt pass B takes 0.383 instead of 0.334 ms.)  The branch around the load stays: a form without it (idle lanes read one shared
     // element) is 4 % faster when pass B runs alone (scripts/bench_b.hip) and 7 % slower behind pass A.
-    const unsigned band_elems = ((unsigned)W << tyshift) * (unsigned)Dp;     // (< 2^32: the launch sees to it)
+    const unsigned band_elems = ((unsigned)Wc << tyshift) * (unsigned)DpL;   // (< 2^32: the launch sees to it)
     const int tymask = (1 << tyshift) - 1;
     auto ld = [&](int row, float(&v)[VPL]) {
         if (need) {
             const int r = clampi(row, H);
-            const size_t off = (size_t)(unsigned)(r >> tyshift) * band_elems + (unsigned)((r & tymask) * Dp);
+            const size_t off = (size_t)(unsigned)(r >> tyshift) * band_elems + (unsigned)((r & tymask) * DpL);
             load_row<VPL>(T + off + j, v);
         } else {
 #pragma unroll
@@ -152,6 +165,25 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
         key_lo = (lane != slot) ? key_lo : d;           // (this way round the scalars need no copy to a VGPR)
         key_hi = (lane != slot) ? key_hi : m;
     };
+    // PAIR: one minimum per half-wave (lanes 31 and 63 after five DPP steps), one key per pixel column
+    auto row_key_pair = [&](int s, int bi, int slot) {
+        int v = s;
+        v = dpp_min<0x111, 0xF>(v);                     // row_shr:1
+        v = dpp_min<0x112, 0xF>(v);                     // row_shr:2
+        v = dpp_min<0x114, 0xF>(v);                     // row_shr:4
+        v = dpp_min<0x118, 0xF>(v);                     // row_shr:8
+        v = dpp_min<0x142, 0xA>(v);                     // row_bcast:15
+        const int m0 = __builtin_amdgcn_readlane(v, 31), m1 = __builtin_amdgcn_readlane(v, 63);
+        const unsigned e0 = (unsigned)__builtin_amdgcn_ballot_w64(s == m0);
+        const unsigned e1 = (unsigned)(__builtin_amdgcn_ballot_w64(s == m1) >> 32);
+        const int w0 = __builtin_ctz(e0), w1 = __builtin_ctz(e1);      // (never zero: each minimum sits in its half)
+        const int d0 = d_first + w0 * 4 + __builtin_amdgcn_readlane(bi, w0);
+        const int d1 = d_first + w1 * 4 + __builtin_amdgcn_readlane(bi, 32 + w1);
+        const bool upper = lane >= 32;
+        const int d = upper ? d1 : d0, m = upper ? m1 : m0;
+        key_lo = (klane != slot) ? key_lo : d;
+        key_hi = (klane != slot) ? key_hi : m;
+    };
     // slot = lane that keeps the key of this row
     auto step = [&](const float(&od)[VPL], const float(&nw)[VPL], int slot, int y) {
         if constexpr (STORE) {
@@ -172,8 +204,12 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
             key_hi += s;
             return;
         }
-        int m = wave_min_i32(s);
-        row_key(s, bi, m, slot);
+        if constexpr (PAIR) {
+            row_key_pair(s, bi, slot);
+        } else {
+            int m = wave_min_i32(s);
+            row_key(s, bi, m, slot);
+        }
     };
     // (Two rows at once with their two DPP chains interleaved, so that one chain's step fills the other's
     // wait states, was measured: 100 fewer s_nop per 27 rows, 136 instead of 128 VGPRs, pass B 0.344 instead
@@ -190,16 +226,17 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                     kout[0] = make_key(key_hi, key_lo);
                 return;
             }
+            const bool col = x < W;                     // (PAIR: kout / kbuf belong to the lane's own column)
             if (kb_rows == 0) {                         // unbuffered (no dynamic LDS given)
-                if (lane < GRP && g0 + lane < H)
-                    kout[g0 + lane] = make_key(key_hi, key_lo);
+                if (klane < GRP && g0 + klane < H && col)
+                    kout[g0 + klane] = make_key(key_hi, key_lo);
                 return;
             }
-            if (lane < GRP)
-                kbuf[g0 - kb_first + lane] = make_key(key_hi, key_lo);
+            if (klane < GRP)
+                kbuf[g0 - kb_first + klane] = make_key(key_hi, key_lo);
             if (g0 + GRP - kb_first == kb_rows || last) {
-                const int n = min(kb_rows, H - kb_first);
-                for (int i = lane; i < n; i += 64)
+                const int n = col ? min(kb_rows, H - kb_first) : 0;
+                for (int i = klane; i < n; i += KLANES)
                     kout[kb_first + i] = kbuf[i];
                 kb_first += kb_rows;
             }

@@ -42,7 +42,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // glev = levels per lane of the pass B that follows (1, 2 or 4): the granule of the store predicate.
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 
-template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
+template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))   // two waves per SIMD exist at most
 void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
@@ -61,8 +61,11 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     float *rl = (float *)(ml + nmatch);                // reference value of positions R0 ..
     const int W = a.W, D = a.D;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const int y = blockIdx.x;
-    const int kc = blockIdx.y * CW;                    // first level of this workgroup
+    // workgroup index = row * chunks + chunk: the chunks of a row are dispatched together, so the halves /
+    // quarters of the row's slab lines are written at about the same time whatever the occupancy
+    const int nck = Dp / CW;
+    const int y = (int)blockIdx.x / nck;
+    const int kc = ((int)blockIdx.x - y * nck) * CW;   // first level of this workgroup
     const int kq = (wib * 64 + lane) * LPL;            // first level of this lane inside the chunk
     // lanes beyond D shadow the last live lane, so disp[i] = disp[0] + i * DS in every lane
     const int Dl = (D + LPL - 1) / LPL * LPL;
@@ -173,12 +176,36 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     // workgroup), a wave-uniform byte offset per step and a 32-bit lane offset.  Lanes beyond D write what
     // the lane they shadow writes, to the same place; an offset of `oob` (= the descriptor's size) makes
     // the hardware drop the store.
-    const unsigned xsb = ((unsigned)Dp << tyshift) * (unsigned)sizeof(float);   // bytes between consecutive x
-    const int oob = (int)((unsigned)W * xsb);
-    const __amdgpu_buffer_rsrc_t trs =
-        __builtin_amdgcn_make_buffer_rsrc(T + slab_row_offset(y, W, Dp, tyshift) + kc, 0, oob, 0x00020000);
+    // PAIRED (128-level slabs, one wave per row): the slab keeps the 128 levels of columns 2c and 2c + 1 side by
+    // side -- T[band][c][ty][x & 1][128], i.e. a slab of (W + 1) / 2 "columns" of 256 floats -- so that pass B
+    // reads a row of two columns with one 1-KiB wave load (smhip_fused_b.h, PAIR).  Step x then lies at
+    // (x >> 1) * pair stride + (x & 1) * 512 bytes instead of x * xsb.
+    static_assert(!PAIRED || (NW == 1 && LPL == 2), "paired layout: 128-level slabs");
+    const unsigned xsb = ((unsigned)(PAIRED ? 256 : Dp) << tyshift) * (unsigned)sizeof(float);   // bytes between consecutive x (PAIRED: pairs)
+    const int oob = (int)((unsigned)(PAIRED ? (W + 1) / 2 : W) * xsb);
+    const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+        T + (PAIRED ? slab_row_offset(y, (W + 1) / 2, 256, tyshift) : slab_row_offset(y, W, Dp, tyshift)) + kc, 0, oob,
+        0x00020000);
     const int lane_off = (kbase - kc) * 4;
     unsigned tb = 0;                                   // byte offset of the current block's first step
+    int px = 0;                                        // PAIRED: parity of that step's x
+    // byte offset of step s of the current block / moving on by one block of WIN (odd) steps
+    auto soff = [&](int s) -> unsigned {
+        if constexpr (!PAIRED)
+            return tb + s * xsb;
+        else
+            return tb + (px ? (unsigned)((s + 1) >> 1) * xsb - (unsigned)(s & 1) * 512u
+                            : (unsigned)(s >> 1) * xsb + (unsigned)(s & 1) * 512u);
+    };
+    auto next_block = [&]() {
+        if constexpr (!PAIRED) {
+            tb += WIN * xsb;
+        } else {
+            static_assert(!PAIRED || (WIN & 1), "odd windows");
+            tb += px ? (unsigned)((WIN + 1) / 2) * xsb - 512u : (unsigned)(WIN / 2) * xsb + 512u;
+            px ^= 1;
+        }
+    };
     auto put = [&](int voff, unsigned off, const float (&acc)[LPL]) {
         if constexpr (LPL == 1) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[0]), trs, voff, off, POL | (ABL >> 4));
@@ -220,9 +247,9 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 ring[i][s] = c;
             }
             if (!(ABL & 1))
-                put(lane_off, tb + s * xsb, acc);
+                put(lane_off, soff(s), acc);
         }
-        tb += WIN * xsb;
+        next_block();
     };
     // one block whose matching positions may leave the row (its reference positions do not): the same
     // walk with clamped pixel fetches, `outside` for the invalid ones and stores switched off per lane
@@ -249,9 +276,9 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 ring[i][s] = c;
             }
             if (!(ABL & 1))
-                put(lane_off + (-(int)!(keep_all || lane_live(xb + s)) & oob), tb + s * xsb, acc);   // (a ?: here became a table in scratch)
+                put(lane_off + (-(int)!(keep_all || lane_live(xb + s)) & oob), soff(s), acc);   // (a ?: here became a table in scratch)
         }
-        tb += WIN * xsb;
+        next_block();
     };
     // the general walk (blocks at the right end of the row, where the reference position is clamped)
     auto general_block = [&](int b) {
@@ -268,10 +295,10 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                     ring[i][s] = c;
                 }
                 if (!((ABL & 1) && x + 2 < W))
-                    put(lane_off + (-(int)!(keep_all || lane_live(x)) & oob), tb + s * xsb, acc);
+                    put(lane_off + (-(int)!(keep_all || lane_live(x)) & oob), soff(s), acc);
             }
         }
-        tb += WIN * xsb;
+        next_block();
     };
 
     Geo g = geometry(0);
@@ -304,7 +331,8 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 }
             }
             put(lane_off, 0, acc);
-            tb = xsb;                                  // tb = offset of step x = 1 + WIN * b from here on
+            tb = PAIRED ? 512u : xsb;                  // tb = offset of step x = 1 + WIN * b from here on
+            px = 1;
         }
 
         int b = c0;

@@ -9,7 +9,7 @@ namespace {
 
 template <int WIN, bool SD, bool CUT, int DS, int POL>
 void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                      hipStream_t stream)
+                      hipStream_t stream, bool paired, long lds_min)
 {
     // 256-level chunks: two waves of two levels per lane; a 128-level slab: one wave
     const int nw = Dp % 256 == 0 ? 2 : 1;
@@ -17,11 +17,23 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
     int cbs = FUSED_F_NI * 64 * nw - WIN - cw;             // staged pixels per thread bounded by FUSED_F_NI
     if (cbs > 480) cbs = 480;
     const int cb = cbs / WIN, nref = cb * WIN + WIN, nmatch = nref + cw;
-    const size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
-    dim3 grid(a.H, Dp / cw);
+    // Workgroups resident per CU, bounded through the LDS a workgroup asks for (160 KB per CU).  All rows take
+    // the same time, so the grid runs in rounds; fewer, fuller rounds of few waves write the slab faster than
+    // every workgroup at once (scripts/exp_occupancy*.sh, profiles/r02_occupancy.log): one-wave workgroups
+    // (128-level slabs) 6 per CU -- 8K 3.11 -> 2.88 ms, 4K 0.848 -> 0.795, 1080p unchanged; two-wave workgroups
+    // 2 per CU from 1280 rows on -- 4K 1.44 -> 1.38 ms, 8K 5.63 -> 5.30 (0.80 of 8 TB/s, the write ceiling),
+    // but 1080 rows (two and a bit rounds of 512) 0.380 -> 0.419, hence the row bound.  lds_min < 0: this policy.
+    size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
+    if (lds_min < 0)
+        lds_min = nw == 1 ? 26 * 1024 : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);   // (four chunks, 8K x 1024: 22.4 against 22.1 ms without)
+    if (lds < (size_t)lds_min) lds = (size_t)lds_min;
+    dim3 grid((unsigned)a.H * (unsigned)(Dp / cw));        // row-major over (row, chunk)
     if (nw == 2)
         fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2, 0, POL><<<grid, 128, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
                                                                                    cb, nref, nmatch, glev);
+    else if (paired)                                       // 128-level slab, columns in pairs (pass B PAIR)
+        fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 1, 0, POL, true><<<grid, 64, lds, stream>>>(
+            a, T, tyshift, Dp, scale, keep_all, cb, nref, nmatch, glev);
     else
         fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 1, 0, POL><<<grid, 64, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
                                                                                   cb, nref, nmatch, glev);
@@ -37,26 +49,26 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
 // kernels keep plain stores: non-temporal ones made the 4-band pass A 6 % slower for a 3 % faster pass B.)
 template <int WIN, bool SD, bool CUT, int DS>
 void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                  hipStream_t stream, int policy)
+                  hipStream_t stream, int policy, bool paired, long lds_min)
 {
     if (policy < 0)
         policy = (size_t)a.W * a.H * Dp * sizeof(float) < ((size_t)4 << 30) ? 16 : 18;
     if (policy == 0)
-        launch_shape_pol<WIN, SD, CUT, DS, 0>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
+        launch_shape_pol<WIN, SD, CUT, DS, 0>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
     else if (policy == 16)
-        launch_shape_pol<WIN, SD, CUT, DS, 16>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
+        launch_shape_pol<WIN, SD, CUT, DS, 16>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
     else
-        launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream);
+        launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
 }
 
 template <int WIN>
 void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
-                   bool cut, hipStream_t stream, int policy)
+                   bool cut, hipStream_t stream, int policy, bool paired, long lds_min)
 {
 #define SMK_F(SD, CUT)                                                                             \
     do {                                                                                           \
-        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy); \
-        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy); \
+        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min); \
+        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min); \
     } while (0)
     if (sd) { if (cut) SMK_F(true, true); else SMK_F(true, false); }
     else    { if (cut) SMK_F(false, true); else SMK_F(false, false); }
@@ -66,11 +78,13 @@ void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, 
 }  // namespace
 
 bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
-                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy)
+                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min)
 {
     if (n_bands != 1 || (a.dstep != 1 && a.dstep != -1) || a.rn != a.rx || Dp % 128 != 0)
         return false;
     if (glev != 2 && glev != 4)
+        return false;
+    if (paired && (Dp != 128 || keep_all || glev != 4))
         return false;
     // buffer-store offsets are 32-bit: the row's extent in the slab and twice that must fit
     const unsigned long long extent = (unsigned long long)a.W * ((unsigned long long)Dp << tyshift) * 4ull;
@@ -78,10 +92,10 @@ bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift
         return false;
     const bool cut = a.cutoff < max_cost;                  // truncation can bite
     switch (window) {
-    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
-    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
-    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
-    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy); break;
+    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
     default: return false;
     }
     return true;

@@ -262,7 +262,8 @@ def test_general_shape_narrow_kernels(gpu_ctx, oracle):
     (41, 30, 1, 128, 9, 1), (40, 64, 1, 100, 5, -1), (7, 12, 4, 65, 4, 1), (130, 35, 1, 96, 11, 1),
     (33, 9, 1, 128, 3, -1), (24, 131, 1, 128, 9, 1), (19, 200, 1, 66, 7, -1), (50, 65, 4, 127, 11, 1),
     (30, 5, 1, 80, 5, 1), (30, 10, 1, 128, 9, 1), (12, 17, 1, 128, 11, -1), (9, 449, 1, 90, 3, 1),
-    (21, 33, 1, 128, 7, 1), (16, 97, 1, 70, 5, 1),
+    (21, 33, 1, 128, 7, 1), (16, 97, 1, 70, 5, 1), (7, 11, 1, 128, 5, 1), (301, 55, 1, 128, 9, -1),
+    (64, 28, 1, 97, 11, 1), (5, 5, 1, 65, 5, -1), (11, 27, 1, 128, 9, 1), (10, 54, 1, 128, 9, 1), (9, 9, 1, 128, 9, 1),
 ])
 def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     """65..128 levels (config 5's per-GPU share is 128): pass B with two levels per lane; heights around the
@@ -273,13 +274,14 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     kw = dict(disp_max=D - 1, frame_ref=fr, frame_match=fm, match_fn=1, match_max=4, match_interval=1,
               aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    for keybuf in (-1, 0, 1):
-        with gpu_ctx.options(keybuf=keybuf):
-            m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
-            disp, best, _ = m.ComputeCorrespondence(left, right)
-        assert m.used_fused
-        assert np.array_equal(disp, odisp), keybuf
-        util.assert_bit_equal(best, obest, "best cost (keybuf %d)" % keybuf)
+    for paired in (1, 0):            # columns in pairs (one band, windows 5..11; forced: the library pairs from 3584 columns on) / one column per wave
+        for keybuf in (-1, 0, 1):
+            with gpu_ctx.options(keybuf=keybuf, paired=paired):
+                m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+                disp, best, _ = m.ComputeCorrespondence(left, right)
+            assert m.used_fused
+            assert np.array_equal(disp, odisp), (paired, keybuf)
+            util.assert_bit_equal(best, obest, "best cost (paired %d, keybuf %d)" % (paired, keybuf))
 
 
 @pytest.mark.parametrize("w,h,b,D,win,sign,step,kw", [
