@@ -43,7 +43,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 
 template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, 2)))   // two waves per SIMD exist at most
+// Waves per SIMD: the kernels of windows up to 9 need 157 VGPRs or fewer, so three waves fit a SIMD; with the
+// bound of two that this kernel had, a CU held four two-wave workgroups, the chip 1024, and config 3's 1080 rows
+// ran as one round of 1024 and a tail of 56: 0.379 ms, against 0.353 ms with all rows resident (1024 rows alone
+// take 0.314 ms, 0.80 of 8 TB/s).  Window 11 takes 180 VGPRs and stays at two.
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, WIN <= 9 ? 3 : 2)))
 void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
                                                                    int nref, int nmatch, int glev)
