@@ -11,4 +11,10 @@ run --window 17 &&
 run --bands 4 &&
 run --width 3840 --height 2160 --disp-total 512 &&
 run --width 7680 --height 4320 --disp-total 128 &&
-run --width 7680 --height 4320 --disp-total 256
+run --width 7680 --height 4320 --disp-total 256 &&
+# (added at the end of round 2, with the occupancy policy)
+run --width 3840 --height 2160 --disp-total 256 &&
+run --width 3840 --height 2160 --disp-total 128 &&
+run --width 1920 --height 1080 --disp-total 512 &&
+run --width 1920 --height 1080 --disp-total 128 &&
+run --width 2560 --height 1440 --disp-total 256

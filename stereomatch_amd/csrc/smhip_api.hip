@@ -297,6 +297,10 @@ int smhip_set_option(smhip_ctx *ctx, int option, int value)
         return fail(SMHIP_EINVAL, "unknown option %d", option);
     if (option == SMHIP_OPT_TYSHIFT && value > 8)
         return fail(SMHIP_EINVAL, "slab band shift %d outside 0..8", value);
+    if (option == SMHIP_OPT_A_LDS_KB && value > 80)
+        return fail(SMHIP_EINVAL, "pass A LDS floor %d KiB above 80 (two workgroups per CU)", value);
+    if (option == SMHIP_OPT_B_WAVES && value > 0 && (value < 6 || value > 16))
+        return fail(SMHIP_EINVAL, "pass B waves per CU %d outside 6..16 (0: no bound)", value);
     // the slab layout and the kernels of calls already queued must not change under them
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->opt[option] = value < 0 ? -1 : value;

@@ -284,6 +284,26 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
             util.assert_bit_equal(best, obest, "best cost (paired %d, keybuf %d)" % (paired, keybuf))
 
 
+@pytest.mark.parametrize("w,h,D,win", [(70, 40, 256, 9), (41, 33, 128, 9), (300, 21, 500, 7), (64, 140, 200, 5)])
+def test_occupancy_options(gpu_ctx, oracle, w, h, D, win):
+    """The bounds on resident workgroups (LDS floors: `a_lds_kb` for the float-lane pass A, `b_waves` for pass B;
+    the library's own policy picks among them by shape) change the launch shape only, never a result."""
+    left, right = synth.noise_pair(w, h, 1, seed=5 + D)
+    kw = dict(disp_max=D - 1, match_fn=1, match_max=5, match_interval=1, aggr_window_size=win)
+    odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
+    for opts in (dict(a_lds_kb=0, b_waves=0), dict(a_lds_kb=54, b_waves=8), dict(a_lds_kb=26, b_waves=6),
+                 dict(a_lds_kb=80, b_waves=16), dict(b_waves=10, keybuf=2), dict(a_lds_kb=41, paired=1)):
+        with gpu_ctx.options(**opts):
+            m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+            disp, best, _ = m.ComputeCorrespondence(left, right)
+        assert m.used_fused
+        assert np.array_equal(disp, odisp), opts
+        util.assert_bit_equal(best, obest, "best cost (%r)" % (opts,))
+    for name, bad in (("a_lds_kb", 81), ("b_waves", 4), ("b_waves", 18)):
+        with pytest.raises(Exception, match="LDS floor|waves per CU"):
+            gpu_ctx.set_option(name, bad)
+
+
 @pytest.mark.parametrize("w,h,b,D,win,sign,step,kw", [
     (1100, 20, 1, 64, 9, 1, 1, dict(match_fn=1, match_interval=1)),           # three chunks
     (1000, 20, 4, 33, 9, 1, 1, dict(match_fn=2, match_max=20)),
