@@ -22,6 +22,12 @@ def main():
     W, H, D = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (3840, 2160, 512)
     reps = 5
     ctx = capi.Context(0)
+    quick = False
+    if len(sys.argv) >= 5:               # a JSON object of context options; "quick": skip the slow optimisers
+        opts = json.loads(sys.argv[4])
+        quick = bool(opts.pop("quick", 0))
+        for k, v in opts.items():
+            ctx.set_option(k, v)
     left, right, _ = synth.scene_pair(W, H, min(D, 256))
     p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
     d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
@@ -64,6 +70,9 @@ def main():
           lambda: ctx.diffusion_run(cost, cost2, disp_src, W, H, D, re, 0.15, 0.5, 4))
     timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
+    if quick:
+        print(json.dumps({"shape": [W, H, D], "ops": out}))
+        return
     timed("opt_so (scan-line opt.)", 4.0 * N + 2.0 * N,
           lambda: ctx.opt_so(cost, W, H, D, re, d_ref, W, 1, 20.0, 8.0, 2.0, disp, best))
     timed("opt_dp (dynamic programming)", 4.0 * N + 2.0 * N,

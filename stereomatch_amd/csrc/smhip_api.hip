@@ -77,6 +77,18 @@ struct smhip_ctx {
 namespace {
 
 // grow-only device workspace slot
+// Dynamic LDS the stage kernels ask for beyond their static arrays: nothing uses it, it bounds the workgroups
+// resident per CU (fewer resident waves stream faster on this part).  Measured on the
+// 3840x2160x512 DSI (scripts/bench_ops.py, profiles/r02_stage_occupancy.log), floors of 0 / 27 / 41 / 54 / 80 KB:
+// binomial _to 7.08 / 6.63 / 6.78 / 8.14 / 13.2 ms, one diffusion iteration 7.53 / 7.34 / 7.04 / 7.33 / 7.33, membrane
+// 7.88 / 7.83 / 7.48 / 7.54 / 7.52 (the same 4-8 % at 1920x1080x256 and x64); every other stage kernel is fastest
+// without a floor (policy_kb 0; the box filter's two walks differ more from process to process than between floors).  SMHIP_OPT_STAGE_LDS_KB >= 0 overrides the floor of all of them.
+static inline size_t stage_lds(const smhip_ctx *ctx, int policy_kb = 0)
+{
+    const int kb = ctx->opt[SMHIP_OPT_STAGE_LDS_KB] >= 0 ? ctx->opt[SMHIP_OPT_STAGE_LDS_KB] : policy_kb;
+    return (size_t)kb * 1024;
+}
+
 int ws_get(smhip_ctx *ctx, int slot, size_t bytes, void **out)
 {
     if (ctx->arena_on) {                 // carve from the static scratch: no hipMalloc, no hipFree
@@ -188,10 +200,10 @@ int prepare_raw(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size
         if (rc) return rc;
         uint8_t *b = (uint8_t *)bt;
         dim3 grid((W * nb + 255) / 256, H);
-        smk::bt_minmax_kernel<<<grid, 256, 0, ctx->stream>>>(d_mtc, b, b + img, pitch, W, H, nb);
+        smk::bt_minmax_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_mtc, b, b + img, pitch, W, H, nb);
         a->mmn = b; a->mmx = b + img;
         if (p->match_interpolated) {
-            smk::bt_minmax_kernel<<<grid, 256, 0, ctx->stream>>>(d_ref, b + 2 * img, b + 3 * img,
+            smk::bt_minmax_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_ref, b + 2 * img, b + 3 * img,
                                                                  pitch, W, H, nb);
             a->rmn = b + 2 * img; a->rmx = b + 3 * img;
         } else {
@@ -225,15 +237,15 @@ int prepare_subpix(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, s
     int16_t *min1 = buf1 + len, *max1 = min1 + len, *min0 = max1 + len, *max0 = min0 + len;
     int cubic = p->match_interp == 3;            // eCubic, StereoParameters.h:44
     dim3 gi((W * nb + 255) / 256, H), gs((n * nb + 255) / 256, H);
-    smk::interp_lines_kernel<<<gi, 256, 0, ctx->stream>>>(d_ref, pitch, buf0, W, H, nb, den, cubic);
-    smk::interp_lines_kernel<<<gi, 256, 0, ctx->stream>>>(d_mtc, pitch, buf1, W, H, nb, den, cubic);
+    smk::interp_lines_kernel<<<gi, 256, stage_lds(ctx), ctx->stream>>>(d_ref, pitch, buf0, W, H, nb, den, cubic);
+    smk::interp_lines_kernel<<<gi, 256, stage_lds(ctx), ctx->stream>>>(d_mtc, pitch, buf1, W, H, nb, den, cubic);
     s->rmn = buf0; s->rmx = nullptr;
     s->mmn = buf1; s->mmx = nullptr;
     if (p->match_interval) {
-        smk::bt_minmax16_kernel<<<gs, 256, 0, ctx->stream>>>(buf1, min1, max1, n, H, nb);
+        smk::bt_minmax16_kernel<<<gs, 256, stage_lds(ctx), ctx->stream>>>(buf1, min1, max1, n, H, nb);
         s->mmn = min1; s->mmx = max1;
         if (p->match_interpolated) {
-            smk::bt_minmax16_kernel<<<gs, 256, 0, ctx->stream>>>(buf0, min0, max0, n, H, nb);
+            smk::bt_minmax16_kernel<<<gs, 256, stage_lds(ctx), ctx->stream>>>(buf0, min0, max0, n, H, nb);
             s->rmn = min0; s->rmx = max0;
         } else {
             s->rmx = buf0;
@@ -297,6 +309,8 @@ int smhip_set_option(smhip_ctx *ctx, int option, int value)
         return fail(SMHIP_EINVAL, "unknown option %d", option);
     if (option == SMHIP_OPT_TYSHIFT && value > 8)
         return fail(SMHIP_EINVAL, "slab band shift %d outside 0..8", value);
+    if (option == SMHIP_OPT_STAGE_LDS_KB && value > 80)
+        return fail(SMHIP_EINVAL, "stage kernels' LDS floor %d KiB above 80", value);
     if (option == SMHIP_OPT_A_LDS_KB && value > 80)
         return fail(SMHIP_EINVAL, "pass A LDS floor %d KiB above 80 (two workgroups per CU)", value);
     if (option == SMHIP_OPT_B_WAVES && value > 0 && (value < 6 || value > 16))
@@ -436,8 +450,8 @@ int smhip_preprocess_blur(smhip_ctx *ctx, uint8_t *d_img, size_t img_pitch, int 
     if (rc) return rc;
     dim3 grid((w * nb + 255) / 256, h);
     for (int i = 0; i < n_iter; i++) {
-        smk::blur121_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_img, (uint8_t *)tmp, img_pitch, w, h, nb);
-        smk::blur14641_v_kernel<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)tmp, d_img, img_pitch, w, h, nb);
+        smk::blur121_h_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_img, (uint8_t *)tmp, img_pitch, w, h, nb);
+        smk::blur14641_v_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>((const uint8_t *)tmp, d_img, img_pitch, w, h, nb);
     }
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -465,7 +479,7 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
         smk::SubpixArgs s;
         rc = prepare_subpix(ctx, d_ref, d_mtc, img_pitch, p, &s);
         if (rc) return rc;
-        smk::raw_costs_subpix_kernel<<<grid, 256, 0, ctx->stream>>>(s, d_cost, row_elems);
+        smk::raw_costs_subpix_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(s, d_cost, row_elems);
         HIP_TRY(hipGetLastError());
         return SMHIP_OK;
     }
@@ -495,7 +509,7 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
             else      smk::raw_costs_rows_kernel<false, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
         }
     } else {
-        smk::raw_costs_kernel<<<grid, 256, 0, ctx->stream>>>(a, d_cost, row_elems);
+        smk::raw_costs_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(a, d_cost, row_elems);
     }
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -530,9 +544,9 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     const int vh = 1, vv = 1;
     const long th = nh / vh, tv = nv / vv;
     (void)vec;
-#define LAUNCH_BOXH(V, WIN) smk::box_h_walk_kernel<V, WIN><<<(unsigned)((th + 255) / 256), 256, 0, ctx->stream>>>( \
+#define LAUNCH_BOXH(V, WIN) smk::box_h_walk_kernel<V, WIN><<<(unsigned)((th + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>( \
         d_cost, (float *)tmp, w, h, nb, row_elems, scale)
-#define LAUNCH_BOXV(V, WIN) smk::box_v_walk_kernel<V, WIN><<<(unsigned)((tv + 255) / 256), 256, 0, ctx->stream>>>( \
+#define LAUNCH_BOXV(V, WIN) smk::box_v_walk_kernel<V, WIN><<<(unsigned)((tv + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>( \
         (const float *)tmp, d_cost, nv, h, row_elems, scale)
 #define LAUNCH_BOX(WIN) do { LAUNCH_BOXH(1, WIN); LAUNCH_BOXV(1, WIN); } while (0)
     switch (win) {               // static windows: register ring, every element loaded once
@@ -542,9 +556,9 @@ int smhip_box_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     case 9: LAUNCH_BOX(9); break;
     case 11: LAUNCH_BOX(11); break;
     default:
-        smk::box_lines_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::box_lines_kernel<<<(unsigned)((nh + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, win, scale);
-        smk::box_lines_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::box_lines_kernel<<<(unsigned)((nv + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, win, scale);
     }
 #undef LAUNCH_BOX
@@ -574,9 +588,9 @@ int smhip_box_filter_border(smhip_ctx *ctx, float *d_cost, int w, int h, int nb,
     if (rc) return rc;
     float scale = (float)(average ? 1.0 / window : 1);
     long nh = (long)h * nb, nv = (long)w * nb;
-    smk::box_lines_border_kernel<<<(unsigned)((nh + 255) / 256), 256, 0, ctx->stream>>>(
+    smk::box_lines_border_kernel<<<(unsigned)((nh + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
         d_cost, (float *)tmp, nh, nb, row_elems, (size_t)nb, w, window, scale, border_x);
-    smk::box_lines_border_kernel<<<(unsigned)((nv + 255) / 256), 256, 0, ctx->stream>>>(
+    smk::box_lines_border_kernel<<<(unsigned)((nv + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
         (const float *)tmp, d_cost, nv, (int)nv, 0, row_elems, h, window, scale, border_y);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -618,15 +632,15 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
 #define LAUNCH_MIN(WIN)                                                                              \
     do {                                                                                             \
         if (vec == 4)                                                                                \
-            smk::minfilter_walk_kernel<4, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
+            smk::minfilter_walk_kernel<4, WIN><<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_src, d_dst, w, nb, h, \
                                                                             row_elems, seglen);     \
         else                                                                                         \
-            smk::minfilter_walk_kernel<1, WIN><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, \
+            smk::minfilter_walk_kernel<1, WIN><<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_src, d_dst, w, nb, h, \
                                                                             row_elems, seglen);     \
     } while (0)
     const int tseg = tile_seglen(ctx, w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
-#define LAUNCH_TMIN(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32><<<tgrid, 256, 0, ctx->stream>>>( \
+#define LAUNCH_TMIN(WIN) smk::tile_walk_kernel<smk::MinOp<WIN>, 32><<<tgrid, 256, stage_lds(ctx), ctx->stream>>>( \
         d_src, d_dst, w, nb, h, row_elems, tseg)
     if (vec == 4 && x_width == y_width && x_width % 2 == 1 && x_width >= 3 && x_width <= 11 &&
         tgrid.y <= 65535 && tgrid.z <= 65535) {
@@ -651,8 +665,8 @@ int smhip_min_filter_to(smhip_ctx *ctx, const float *d_src, float *d_dst, int w,
         if (tmp == d_src || tmp == d_dst)
             return fail(SMHIP_EINVAL, "MinFilter: buffers alias the context workspace");
         dim3 g2((w * nb + 255) / 256, h);
-        smk::min_h_kernel<<<g2, 256, 0, ctx->stream>>>(d_src, (float *)tmp, w, nb, row_elems, x_width);
-        smk::min_v_kernel<<<g2, 256, 0, ctx->stream>>>((const float *)tmp, d_dst, w * nb, h, row_elems,
+        smk::min_h_kernel<<<g2, 256, stage_lds(ctx), ctx->stream>>>(d_src, (float *)tmp, w, nb, row_elems, x_width);
+        smk::min_v_kernel<<<g2, 256, stage_lds(ctx), ctx->stream>>>((const float *)tmp, d_dst, w * nb, h, row_elems,
                                                       y_width);
     }
 #undef LAUNCH_MIN
@@ -686,8 +700,8 @@ int smhip_min_filter(smhip_ctx *ctx, float *d_cost, int w, int h, int nb, size_t
     rc = ws_get(ctx, WS_TMP, bytes, &tmp);
     if (rc) return rc;
     dim3 grid((w * nb + 255) / 256, h);
-    smk::min_h_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems, x_width);
-    smk::min_v_kernel<<<grid, 256, 0, ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems,
+    smk::min_h_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_cost, (float *)tmp, w, nb, row_elems, x_width);
+    smk::min_v_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>((const float *)tmp, d_cost, w * nb, h, row_elems,
                                                     y_width);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -708,12 +722,12 @@ int smhip_convolve_14641_to(smhip_ctx *ctx, const float *d_src, float *d_dst, in
     const int tseg = tile_seglen(ctx, w, h, nb);
     dim3 tgrid((w + 31) / 32, (nb + 31) / 32, (h + tseg - 1) / tseg);
     if (vec == 4 && tgrid.y <= 65535 && tgrid.z <= 65535)
-        smk::tile_walk_kernel<smk::BinomOp, 32><<<tgrid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h,
+        smk::tile_walk_kernel<smk::BinomOp, 32><<<tgrid, 256, stage_lds(ctx, 27), ctx->stream>>>(d_src, d_dst, w, nb, h,
                                                                                row_elems, tseg);
     else if (vec == 4)
-        smk::binomial_walk_kernel<4><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
+        smk::binomial_walk_kernel<4><<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
     else
-        smk::binomial_walk_kernel<1><<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
+        smk::binomial_walk_kernel<1><<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_src, d_dst, w, nb, h, row_elems, seglen);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -752,7 +766,7 @@ int smhip_diffusion_iter(smhip_ctx *ctx, const float *d_src, float *d_dst, const
     const bool mem = beta > 0.0f;
     int vec = walk_vec(nb, row_elems, d_src, d_dst, mem ? d_cost0 : nullptr);
     dim3 grid = walk_grid(w, nb, h, vec, seglen);
-#define LAUNCH_DIFF(V, M) smk::diffusion_walk_kernel<V, M><<<grid, 256, 0, ctx->stream>>>( \
+#define LAUNCH_DIFF(V, M) smk::diffusion_walk_kernel<V, M><<<grid, 256, stage_lds(ctx, 41), ctx->stream>>>( \
         d_src, d_dst, d_cost0, w * nb, nb, h, row_elems, seglen, lambda, a, lb)
     if (vec == 4) { if (mem) LAUNCH_DIFF(4, true); else LAUNCH_DIFF(4, false); }
     else          { if (mem) LAUNCH_DIFF(1, true); else LAUNCH_DIFF(1, false); }
@@ -818,9 +832,9 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
         dim3 grid((w + (smk::MULTI_TXT - 2 * K) - 1) / (smk::MULTI_TXT - 2 * K), gy, gz);
 #define LAUNCH_DM(KK)                                                                              \
         do {                                                                                       \
-            if (mem) smk::diffusion_multi_kernel<KK, true><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(  \
+            if (mem) smk::diffusion_multi_kernel<KK, true><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(  \
                 cur, oth, d_cost0, w, nb, h, row_elems, tseg, lambda, a, lb);                      \
-            else smk::diffusion_multi_kernel<KK, false><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(     \
+            else smk::diffusion_multi_kernel<KK, false><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(     \
                 cur, oth, d_cost0, w, nb, h, row_elems, tseg, lambda, a, lb);                      \
         } while (0)
         switch (K) {
@@ -872,9 +886,9 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         } else {
             dim3 grid((w + (smk::MULTI_TXT - 4 * K) - 1) / (smk::MULTI_TXT - 4 * K), gy, gz);
             switch (K) {
-            case 2: smk::binomial_multi_kernel<2><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
-            case 3: smk::binomial_multi_kernel<3><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
-            default: smk::binomial_multi_kernel<4><<<grid, smk::MULTI_TXT * 8, 0, ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            case 2: smk::binomial_multi_kernel<2><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            case 3: smk::binomial_multi_kernel<3><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            default: smk::binomial_multi_kernel<4><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
             }
         }
         left -= K;
@@ -900,7 +914,7 @@ int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip
             return fail(SMHIP_EINVAL, "width*levels exceeds 2^31");
         int den = p->disp_den, n = den * (p->width - 1) + 1;
         dim3 grid((p->width * p->disp_n + 255) / 256, p->height);
-        smk::pad_costs_subpix_kernel<<<grid, 256, 0, ctx->stream>>>(
+        smk::pad_costs_subpix_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(
             d_cost, row_elems, p->width, p->disp_n, n, den, -p->frame_diff_sign * (den * p->disp_min),
             -p->frame_diff_sign * p->disp_num, smhip_match_outside(p));
         HIP_TRY(hipGetLastError());
@@ -914,7 +928,7 @@ int smhip_pad_costs(smhip_ctx *ctx, float *d_cost, size_t row_elems, const smhip
     if (maxpad == 0)
         return SMHIP_OK;
     dim3 grid((p->disp_n * maxpad + 255) / 256, p->height);
-    smk::pad_costs_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost, row_elems, p->width, p->disp_n, disp0,
+    smk::pad_costs_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_cost, row_elems, p->width, p->disp_n, disp0,
                                                         dstep, maxpad, smhip_match_outside(p));
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -936,17 +950,17 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
             long waves = (n_pix + run - 1) / run;
             unsigned blocks = (unsigned)((waves + 3) / 4);
             int nv = (nb + 255) / 256;
-            if (nv == 1)      smk::wta_vec_kernel<1><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
-            else if (nv == 2) smk::wta_vec_kernel<2><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
-            else if (nv == 3) smk::wta_vec_kernel<3><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
-            else              smk::wta_vec_kernel<4><<<blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            if (nv == 1)      smk::wta_vec_kernel<1><<<blocks, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else if (nv == 2) smk::wta_vec_kernel<2><<<blocks, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else if (nv == 3) smk::wta_vec_kernel<3><<<blocks, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
+            else              smk::wta_vec_kernel<4><<<blocks, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best, run);
         } else if (nb >= 8) {
             int seg = 2;                               // lanes per pixel: the power of two >= nb / 4
             while (4 * seg < nb) seg *= 2;
             const int ppt = 4;                         // pixels per thread (8 measured 2.5x slower)
             const int per_block = ppt * 256 / seg;
             dim3 grid((unsigned)((w + per_block - 1) / per_block), h);
-#define LAUNCH_WS(S) smk::wta_seg_kernel<S, ppt><<<grid, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best)
+#define LAUNCH_WS(S) smk::wta_seg_kernel<S, ppt><<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, d_disp, d_best)
             switch (seg) {
             case 2: LAUNCH_WS(2); break;
             case 4: LAUNCH_WS(4); break;
@@ -956,16 +970,16 @@ int smhip_wta(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size_t 
             }
 #undef LAUNCH_WS
         } else {
-            smk::wta_thread_vec_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+            smk::wta_thread_vec_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
                 d_cost, w, h, nb, row_elems, d_disp, d_best);
         }
     } else if (nb >= 64) {
         long blocks = (n_pix + 3) / 4;
         if (blocks > 256 * 32) blocks = 256 * 32;
-        smk::wta_wave_kernel<<<(unsigned)blocks, 256, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems,
+        smk::wta_wave_kernel<<<(unsigned)blocks, 256, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems,
                                                                         d_disp, d_best);
     } else {
-        smk::wta_thread_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::wta_thread_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             d_cost, w, h, nb, row_elems, d_disp, d_best);
     }
     HIP_TRY(hipGetLastError());
@@ -982,7 +996,7 @@ int smhip_subpixel_fit(smhip_ctx *ctx, const float *d_src, float *d_dst, float *
     if (!d_dst || !d_min || !d_cert || d_dst == d_src)
         return fail(SMHIP_EINVAL, "AggrSubPixelFit: needs distinct source, destination, min and cert buffers");
     dim3 grid((w * nb + 255) / 256, h);
-    smk::subpixel_fit_kernel<<<grid, 256, 0, ctx->stream>>>(d_src, d_dst, d_min, d_cert, w, nb, row_elems,
+    smk::subpixel_fit_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_src, d_dst, d_min, d_cert, w, nb, row_elems,
                                                            match_outside);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -1003,7 +1017,7 @@ int smhip_collapse(smhip_ctx *ctx, const float *d_cost1, const float *d_min1, in
     if (df < 2 || (nb1 - 1) % df != 0 || nb2 != (nb1 - 1) / df + 1)   // StcAggregate.cpp:139-146
         return fail(SMHIP_EINVAL, "AggrCollapse: %d levels at step 1/%d do not collapse to %d", nb1, df, nb2);
     dim3 grid((w * nb2 + 255) / 256, h);
-    smk::collapse_kernel<<<grid, 256, 0, ctx->stream>>>(d_cost1, d_min1, w, nb1, row_elems1, df, nb2,
+    smk::collapse_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(d_cost1, d_min1, w, nb1, row_elems1, df, nb2,
                                                        row_elems2, disp_step, d_cost2, d_min2);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -1028,7 +1042,7 @@ int smhip_refine(smhip_ctx *ctx, const int32_t *d_disp, const float *d_cost, con
         if (rc) return rc;
     }
     long n_pix = (long)w * h;
-    smk::refine_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+    smk::refine_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
         d_cost, d_min, d_disp, w, h, nb, row_elems, disp_step, disp_min, mode, d_fdisp);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -1052,7 +1066,7 @@ int smhip_match_quality(smhip_ctx *ctx, const float *d_cost, const float *d_cert
     if (norm_bands != 1 && norm_bands != 3)
         return fail(SMHIP_EINVAL, "ComputeMatchQuality: costs are normalised by 1 or 3 bands (%d given)", norm_bands);
     long n_pix = (long)w * h;
-    smk::match_quality_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+    smk::match_quality_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
         d_cost, d_cert, d_fdisp, w, h, nb, row_elems, cert_row_elems, disp_min, disp_step_inv,
         quality_mode == 2, use_fit != 0, norm_bands, take_sqrt != 0, d_final_cost, d_certainty);
     HIP_TRY(hipGetLastError());
@@ -1077,9 +1091,9 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
     rc = ws_get(ctx, WS_TMP, (size_t)w * h * nb * sizeof(int16_t), &trans);
     if (rc) return rc;
     dim3 gs((w + 255) / 256, h);
-    smk::smooth_h_kernel<<<gs, 256, 0, ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
+    smk::smooth_h_kernel<<<gs, 256, stage_lds(ctx), ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
                                                      opt_grad_thresh, opt_grad_penalty, (float *)smooth);
-#define LAUNCH_SO(NV) smk::opt_so_kernel<NV><<<h, 64, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, \
+#define LAUNCH_SO(NV) smk::opt_so_kernel<NV><<<h, 64, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, \
         (const float *)smooth, (int16_t *)trans, d_disp)
     if (nb <= 64)       LAUNCH_SO(1);
     else if (nb <= 128) LAUNCH_SO(2);
@@ -1089,7 +1103,7 @@ int smhip_opt_so(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
 #undef LAUNCH_SO
     if (d_best) {
         long n_pix = (long)w * h;
-        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             d_cost, w, h, nb, row_elems, d_disp, d_best);
     }
     HIP_TRY(hipGetLastError());
@@ -1115,10 +1129,10 @@ int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
     rc = ws_get(ctx, WS_TMP, (size_t)w * h * nb, &trans);
     if (rc) return rc;
     dim3 gs((w + 255) / 256, h);
-    smk::smooth_h_kernel<<<gs, 256, 0, ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
+    smk::smooth_h_kernel<<<gs, 256, stage_lds(ctx), ctx->stream>>>(d_ref, img_pitch, w, h, img_bands, opt_smoothness,
                                                      opt_grad_thresh, opt_grad_penalty, (float *)smooth);
     const float oc = (float)opt_occlusion_cost;      // ocL = ocR, StcOptDP.cpp:116-117
-#define LAUNCH_DP(NV) smk::opt_dp_kernel<NV><<<h, 64, 0, ctx->stream>>>(d_cost, w, h, nb, row_elems, \
+#define LAUNCH_DP(NV) smk::opt_dp_kernel<NV><<<h, 64, stage_lds(ctx), ctx->stream>>>(d_cost, w, h, nb, row_elems, \
         (const float *)smooth, oc, (uint8_t *)trans, d_disp)
     if (nb <= 64)       LAUNCH_DP(1);
     else if (nb <= 128) LAUNCH_DP(2);
@@ -1128,7 +1142,7 @@ int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int nb, size
 #undef LAUNCH_DP
     if (d_best) {
         long n_pix = (long)w * h;
-        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::gather_best_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             d_cost, w, h, nb, row_elems, d_disp, d_best);
     }
     HIP_TRY(hipGetLastError());
@@ -1240,7 +1254,7 @@ int smhip_bayesian_iter(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_
     bayes_smooth(ctx, d_cost, d_cost2, iter == 0 ? d_cost0 : nullptr, scale_cost, nullptr, nullptr, mu, w, h, nb,
                  row_elems);
     dim3 ge((w * nb + 255) / 256, h);
-    smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(d_cost, d_cost2, d_cost0, w, nb, h, row_elems, mu);
+    smk::bayes_update_kernel<<<ge, 256, stage_lds(ctx), ctx->stream>>>(d_cost, d_cost2, d_cost0, w, nb, h, row_elems, mu);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -1266,7 +1280,7 @@ int smhip_bayesian_run(smhip_ctx *ctx, float *d_cost, float *d_cost2, float *d_c
         float *t = es; es = other; other = t;
     }
     dim3 ge((w * nb + 255) / 256, h);
-    smk::bayes_update_kernel<<<ge, 256, 0, ctx->stream>>>(other, es, d_cost0, w, nb, h, row_elems, mu);
+    smk::bayes_update_kernel<<<ge, 256, stage_lds(ctx), ctx->stream>>>(other, es, d_cost0, w, nb, h, row_elems, mu);
     *result_in_b = (other == d_cost2);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -1280,7 +1294,7 @@ int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int heig
     if (!d_keys || width < 1 || height < 1 || (!d_disp && !d_best))
         return fail(SMHIP_EINVAL, "bad decode request");
     dim3 grid((width + 31) / 32, (height + 31) / 32);
-    smk::keys_decode_t_kernel<<<grid, 256, 0, ctx->stream>>>((const long long *)d_keys, width, height,
+    smk::keys_decode_t_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>((const long long *)d_keys, width, height,
                                                             d_disp, d_best);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
@@ -1454,7 +1468,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 #undef LAUNCH_A3
     } else {
         long chains = (long)H * Dp;
-        smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             a, (float *)T, trow, Dp, window, scale);
     }
     if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
@@ -1528,7 +1542,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             default: LAUNCH_BW(0) break;
             }
         } else {                     // aggregated DSI out: 4 levels per lane, d_count % 4 == 0
-#define LAUNCH_BS(WIN) smk::fused_boxv_wta_vpl_kernel<WIN, 4, 0, true><<<gb, 64 * wpb, 0, ctx->stream>>>( \
+#define LAUNCH_BS(WIN) smk::fused_boxv_wta_vpl_kernel<WIN, 4, 0, true><<<gb, 64 * wpb, stage_lds(ctx), ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,           \
         d_first, x_per_xcd, nullptr, 0, d_dsi, dsi_row_elems)
             switch (window) {
@@ -1547,7 +1561,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         int pix_per_blk = 256 / CH;
         unsigned gx = (unsigned)((W + pix_per_blk - 1) / pix_per_blk);
 #define LAUNCH_B(SEG)                                                                        \
-    smk::fused_boxv_wta_kernel<SEG><<<gx, 256, 0, ctx->stream>>>(                            \
+    smk::fused_boxv_wta_kernel<SEG><<<gx, 256, stage_lds(ctx), ctx->stream>>>(                            \
         (const float *)T, trow, W, H, d_count, window, scale, a.disp0, a.dstep, outside, d_first, kout)
         switch (CH) {
         case 2: LAUNCH_B(2); break;
@@ -1559,7 +1573,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 #undef LAUNCH_B
     }
     if (n_chunks > 1 && !keep_all)
-        smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, 0, ctx->stream>>>(
+        smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             kout, n_chunks, n_pix, (long long *)d_keys);
     if (prof) {
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
@@ -1629,7 +1643,7 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     dim3 grid((w + txo - 1) / txo, (h + seg - 1) / seg);
     if (grid.y > 65535)
         return fail(SMHIP_EINVAL, "min filter + WTA keys: more than %d rows", 65535 * seg);
-#define LAUNCH_MW(WIN) smk::min_wta_tile_kernel<WIN><<<grid, 512, 0, ctx->stream>>>(d_cost, w, d_count, h, row_elems, seg, pw)
+#define LAUNCH_MW(WIN) smk::min_wta_tile_kernel<WIN><<<grid, 512, stage_lds(ctx), ctx->stream>>>(d_cost, w, d_count, h, row_elems, seg, pw)
     switch (min_window) {
     case 3: LAUNCH_MW(3); break;
     case 5: LAUNCH_MW(5); break;
@@ -1671,7 +1685,7 @@ int smhip_pad_wta_keys(smhip_ctx *ctx, float *d_cost, size_t row_elems, const sm
     rc = smhip_wta(ctx, d_cost, w, h, d_count, row_elems, disp, best);
     if (rc) return rc;
     dim3 grid((w + 31) / 32, (h + 31) / 32);
-    smk::keys_encode_t_kernel<<<grid, 256, 0, ctx->stream>>>(disp, best, w, h, d_first, (long long *)d_keys);
+    smk::keys_encode_t_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(disp, best, w, h, d_first, (long long *)d_keys);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
