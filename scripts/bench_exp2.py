@@ -18,6 +18,9 @@ def main():
     W, H, D = (int(a) for a in sys.argv[1:4]) if len(sys.argv) >= 4 else (1920, 1080, 256)
     reps = 20
     ctx = capi.Context(0)
+    if len(sys.argv) >= 5:               # a JSON object of context options
+        for k, v in json.loads(sys.argv[4]).items():
+            ctx.set_option(k, v)
     left, right, _ = synth.scene_pair(W, H, min(D, 256))
     p = capi.match_params(W, H, 1, D, match_fn=2, match_max=20)
     d_ref, d_mtc = ctx.upload(left), ctx.upload(right)

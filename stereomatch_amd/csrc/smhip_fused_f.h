@@ -42,12 +42,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // glev = levels per lane of the pass B that follows (1, 2 or 4): the granule of the store predicate.
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 
-template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
+template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false, bool W3 = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
 // Waves per SIMD: the kernels of windows up to 9 need 157 VGPRs or fewer, so three waves fit a SIMD; with the
 // bound of two that this kernel had, a CU held four two-wave workgroups, the chip 1024, and config 3's 1080 rows
 // ran as one round of 1024 and a tail of 56: 0.379 ms, against 0.353 ms with all rows resident (1024 rows alone
-// take 0.314 ms, 0.80 of 8 TB/s).  Window 11 takes 180 VGPRs and stays at two.
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(1, WIN <= 9 ? 3 : 2)))
+// take 0.314 ms, 0.80 of 8 TB/s).  Window 11 takes 180 VGPRs: W3 = true forces it under 168 (44-60 bytes of scratch
+// per lane), which costs about 3 % and saves the tail (config 3: 0.379 -> 0.363 ms) -- used when no LDS floor bounds
+// the residency anyway (frames below 1280 rows).
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 1, (WIN <= 9 || W3) ? 3 : 2)))
 void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
                                                                    int nref, int nmatch, int glev)

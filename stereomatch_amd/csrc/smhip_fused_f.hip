@@ -28,7 +28,11 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
         lds_min = nw == 1 ? 26 * 1024 : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);   // (four chunks, 8K x 1024: 22.4 against 22.1 ms without)
     if (lds < (size_t)lds_min) lds = (size_t)lds_min;
     dim3 grid((unsigned)a.H * (unsigned)(Dp / cw));        // row-major over (row, chunk)
-    if (nw == 2)
+    if (nw == 2 && WIN > 9 && a.H < 1280) {                // all rows resident: three waves per SIMD (see the kernel)
+        if constexpr (WIN > 9)
+            fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2, 0, POL, false, true><<<grid, 128, lds, stream>>>(
+                a, T, tyshift, Dp, scale, keep_all, cb, nref, nmatch, glev);
+    } else if (nw == 2)
         fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2, 0, POL><<<grid, 128, lds, stream>>>(a, T, tyshift, Dp, scale, keep_all,
                                                                                    cb, nref, nmatch, glev);
     else if (paired)                                       // 128-level slab, columns in pairs (pass B PAIR)
