@@ -1,9 +1,18 @@
 // smhip_fused_f.hip -- instantiations and dispatch of the float-lane pass A (smhip_fused_f.h).
 // Built with -fno-slp-vectorize (see the header of smhip_fused_f.h) and linked into libsmhip.so.
+// The file is compiled five times (__graft_entry__.build_hip): once per window with -DSMK_F_WIN=5 / 7 / 9 / 11,
+// each giving launch_fused_f_window<WIN>, and once without for the dispatcher -- the instantiations of one
+// window take about a minute of compile time, and the build runs them side by side.
 #include "smhip_fused_f.h"
 #include "smhip_fused_f_launch.h"
 
 namespace smk {
+
+template <int WIN>
+void launch_fused_f_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
+                           bool cut, hipStream_t stream, int policy, bool paired, long lds_min);
+
+#ifdef SMK_F_WIN
 
 namespace {
 
@@ -65,10 +74,13 @@ void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, i
         launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
 }
 
-template <int WIN>
-void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
-                   bool cut, hipStream_t stream, int policy, bool paired, long lds_min)
+}  // namespace
+
+template <>
+void launch_fused_f_window<SMK_F_WIN>(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
+                                      bool sd, bool cut, hipStream_t stream, int policy, bool paired, long lds_min)
 {
+    constexpr int WIN = SMK_F_WIN;
 #define SMK_F(SD, CUT)                                                                             \
     do {                                                                                           \
         if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min); \
@@ -79,7 +91,7 @@ void launch_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, 
 #undef SMK_F
 }
 
-}  // namespace
+#else   // the dispatcher
 
 bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
                              int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min)
@@ -96,13 +108,15 @@ bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift
         return false;
     const bool cut = a.cutoff < max_cost;                  // truncation can bite
     switch (window) {
-    case 5: launch_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 7: launch_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 9: launch_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 11: launch_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 5: launch_fused_f_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 7: launch_fused_f_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 9: launch_fused_f_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 11: launch_fused_f_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
     default: return false;
     }
     return true;
 }
+
+#endif
 
 }  // namespace smk
