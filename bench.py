@@ -257,7 +257,7 @@ def main():
                 r["ms_per_launch"] = stats(per)
             return r
         one_band_unit = b == 1                       # the float-lane pass A covers it (window 5..11)
-        name_a = "fused_rawbox_h_f_kernel" if one_band_unit and win in (5, 7, 9, 11) else "fused_rawbox_h_lds_kernel"
+        name_a = "fused_rawbox_h_f_kernel" if one_band_unit and win in (3, 5, 7, 9, 11) else "fused_rawbox_h_lds_kernel"
         ka = roof(name_a, bytes_a, ta, per_call[0])
         kb = roof("fused_boxv_wta_vpl_kernel", bytes_b, tb, per_call[1])
         dominant = ka if ta >= tb else kb

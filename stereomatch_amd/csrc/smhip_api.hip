@@ -1363,7 +1363,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     bool paired = tuned_a && !keep_all && Dp == 128 && p->n_bands == 1 && ctx->opt[SMHIP_OPT_PAIRED] != 0 &&
                   (W >= 3584 || ctx->opt[SMHIP_OPT_PAIRED] > 0) &&
                   ctx->opt[SMHIP_OPT_CHUNK] < 0 && ctx->opt[SMHIP_OPT_FLOAT_A] != 0 &&
-                  (window == 5 || window == 7 || window == 9 || window == 11);
+                  (window == 3 || window == 5 || window == 7 || window == 9 || window == 11);
     const size_t Wc = paired ? ((size_t)W + 1) / 2 : (size_t)W, DpL = paired ? 256 : (size_t)Dp;
     while (tyshift > 0 && ((((unsigned long long)Wc << tyshift) * (unsigned long long)DpL) >> 32) != 0)
         tyshift--;                                      // pass B multiplies the band size as a 32-bit number
@@ -1425,7 +1425,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "row staging needs %zu bytes of LDS (width %d, window %d, step %d)", lds, W,
                         window, adstep);
-        // one band, unit step, point reference interval, window 5..11: the float-lane kernel
+        // one band, unit step, point reference interval, window 3..11: the float-lane kernel
         // (smhip_fused_f.h, a translation unit of its own); everything else: the integer kernels below
         bool float_a = false;
         if (!chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0) {
@@ -1493,7 +1493,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), b_chunks);
         // keys collect in a wave-private LDS buffer of kb_rows rows (a multiple of the kernel's key group)
         // and go to memory in long runs: stores into the read stream cost HBM bus turn-arounds
-        const int kblk = (window == 3 || window == 5 || window == 7 || window == 9 || window == 11) ? window : 8;
+        const bool b_static = window >= 3 && window <= 17 && (window & 1);
+        const int kblk = smk::passb_blk(b_static ? window : 0);
         const int kgrp = (64 / kblk) * kblk;
         // (two workgroups per CU leave each 80 KB: 36 groups, 8K x 256 5.54 -> 5.42 ms)
         int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (b_policy && b_waves == 8 ? 36 : 18);   // 0: unbuffered
@@ -1512,10 +1513,10 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         case 2: LAUNCH_BT(WIN, 2); break;              \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
-        if (paired) {                // (the float-lane pass A ran: window 5 .. 11, Dp 128, keys out)
+        if (paired) {                // (the float-lane pass A ran: window 3 .. 11, Dp 128, keys out)
             const int xp = (((W + 1) / 2) + 7) / 8;     // column pairs per XCD
             dim3 gp(8 * ((xp + wpb - 1) / wpb), 1);
-            const int pgrp = (32 / window) * window;    // rows per key group of a half-wave
+            const int pgrp = (32 / smk::passb_blk(window)) * smk::passb_blk(window);   // rows per key group of a half-wave
             int pg = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (1134 + pgrp - 1) / pgrp;   // runs of ~9 KB per column, as above
             if (pg > (H + pgrp - 1) / pgrp) pg = (H + pgrp - 1) / pgrp;
             if (pg > 64) pg = 64;                       // 4 waves x 2 columns x 64 groups x 32 rows x 8 B = 128 KB
@@ -1526,6 +1527,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,                      \
         d_first, xp, kout, n_pix, nullptr, 0, prow)
             switch (window) {
+            case 3: LAUNCH_BP(3); break;
             case 5: LAUNCH_BP(5); break;
             case 7: LAUNCH_BP(7); break;
             case 9: LAUNCH_BP(9); break;
@@ -1539,6 +1541,9 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             case 7: LAUNCH_BW(7) break;
             case 9: LAUNCH_BW(9) break;
             case 11: LAUNCH_BW(11) break;
+            case 13: LAUNCH_BW(13) break;
+            case 15: LAUNCH_BW(15) break;
+            case 17: LAUNCH_BW(17) break;
             default: LAUNCH_BW(0) break;
             }
         } else {                     // aggregated DSI out: 4 levels per lane, d_count % 4 == 0
@@ -1551,6 +1556,9 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             case 7: LAUNCH_BS(7); break;
             case 9: LAUNCH_BS(9); break;
             case 11: LAUNCH_BS(11); break;
+            case 13: LAUNCH_BS(13); break;
+            case 15: LAUNCH_BS(15); break;
+            case 17: LAUNCH_BS(17); break;
             default: LAUNCH_BS(0); break;
             }
 #undef LAUNCH_BS

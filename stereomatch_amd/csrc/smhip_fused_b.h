@@ -21,6 +21,9 @@
 
 namespace smk {
 
+// rows per block of pass B for a static window (0: the generic kernel); shared with the host's key-buffer sizing
+constexpr int passb_blk(int win) { return win == 0 ? 8 : win == 3 ? 9 : win == 5 ? 10 : win; }
+
 template <int VPL> struct vecf { typedef float type __attribute__((ext_vector_type(VPL))); };
 template <> struct vecf<1> { typedef float type; };
 
@@ -38,9 +41,11 @@ __device__ __forceinline__ void load_row(const float *p, float (&v)[VPL])
     }
 }
 
-// WIN > 0: static window, blocks of WIN rows, the row leaving the window is the row that
-// entered one block earlier (registers).  WIN == 0: generic window, blocks of 8 rows, the
-// leaving row is re-read.  blockDim.x = 64 * (pixel columns per block), one wave per column.
+// WIN > 0: static window, blocks of passb_blk(WIN) rows (WIN, or a multiple of it for the small windows, so
+// that the rolling prefetch stays about nine rows deep); the row leaving the window is the row that entered
+// WIN rows earlier (registers: this block or the one before).  WIN == 0: generic window, blocks of 8 rows, the
+// leaving row is re-read.  Windows 13 .. 17 hold 156 .. 204 row registers: two waves per SIMD, which is what
+// the occupancy policy wants anyway (smhip_api.hip).  blockDim.x = 64 * (pixel columns per block), one wave per column.
 // STORE = true: the same walk, but instead of PadCosts + WTA every aggregated row is written to
 // the DSI S[y][x][D] (reference layout, row stride s_row_elems; D % VPL == 0): RawCosts + one
 // AggrBox with 12 bytes per voxel instead of 20.  All levels are kept (the min filter that may
@@ -61,7 +66,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
 {
     static_assert(!PAIR || (VPL == 4 && !STORE), "paired columns: four levels per lane, keys out");
     extern __shared__ __attribute__((aligned(16))) long long kbuf_all[];
-    constexpr int BLK = WIN ? WIN : 8;
+    constexpr int BLK = passb_blk(WIN);
+    constexpr int OFF = WIN ? BLK - WIN : 0;           // the block before: its last WIN rows are still needed
     constexpr int KLANES = PAIR ? 32 : 64;             // lanes that keep the keys of one pixel column
     constexpr int GRP = (KLANES / BLK) * BLK;          // rows per key store (63 for WIN 9; PAIR: 27)
     constexpr int CH = 64 * VPL;
@@ -247,18 +253,22 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
         float b0[BLK][VPL], b1[BLK][VPL], b2[BLK][VPL];
 #pragma unroll
         for (int r = 0; r < BLK; r++) {
-            ld(r + pl, b0[r]);
+            if (r < WIN)
+                ld(r + pl, b0[OFF + r]);
             ld(r + pr, b1[r]);
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++)
-            b0[0][i] = b1[0][i];   // y = 0 adds scale*(-a + a) = +0: the first value stays the window sum
+            b0[OFF][i] = b1[0][i];   // y = 0 adds scale*(-a + a) = +0: the first value stays the window sum
         auto block = [&](float(&prv)[BLK][VPL], float(&cur)[BLK][VPL], float(&nxt)[BLK][VPL], int yb) {
             const int slot0 = yb % GRP;
 #pragma unroll
             for (int r = 0; r < BLK; r++) {
                 ld(yb + BLK + r + pr, nxt[r]);          // rolling prefetch, one block ahead
-                step(prv[r], cur[r], slot0 + r, yb + r);
+                if (r >= WIN)                           // the row that entered WIN rows ago
+                    step(cur[r - (r >= WIN ? WIN : 0)], cur[r], slot0 + r, yb + r);
+                else
+                    step(prv[OFF + r], cur[r], slot0 + r, yb + r);
             }
             flush(yb);
         };

@@ -1,6 +1,6 @@
 // smhip_fused_f.hip -- instantiations and dispatch of the float-lane pass A (smhip_fused_f.h).
 // Built with -fno-slp-vectorize (see the header of smhip_fused_f.h) and linked into libsmhip.so.
-// The file is compiled five times (__graft_entry__.build_hip): once per window with -DSMK_F_WIN=5 / 7 / 9 / 11,
+// The file is compiled six times (__graft_entry__.build_hip): once per window with -DSMK_F_WIN=3 / 5 / 7 / 9 / 11,
 // each giving launch_fused_f_window<WIN>, and once without for the dispatcher -- the instantiations of one
 // window take about a minute of compile time, and the build runs them side by side.
 #include "smhip_fused_f.h"
@@ -108,6 +108,7 @@ bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift
         return false;
     const bool cut = a.cutoff < max_cost;                  // truncation can bite
     switch (window) {
+    case 3: launch_fused_f_window<3>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
     case 5: launch_fused_f_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
     case 7: launch_fused_f_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
     case 9: launch_fused_f_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;

@@ -9,7 +9,7 @@
 namespace smk {
 
 // Launches pass A in its float-lane form on `stream` when the configuration is one it covers: one band,
-// |dstep| == 1, reference interval a point (a.rn == a.rx), window 5 / 7 / 9 / 11, Dp a multiple of 128,
+// |dstep| == 1, reference interval a point (a.rn == a.rx), window 3 / 5 / 7 / 9 / 11, Dp a multiple of 128,
 // slab row extent below 2 GiB.  paired: the 128-level slab with its columns in pairs (smhip_fused_f.h, PAIRED;
 // needs Dp == 128, glev == 4, keys out).  glev = levels per lane of the pass B that follows.  Returns false
 // (nothing launched) otherwise; the caller then takes fused_rawbox_h_lds_kernel.

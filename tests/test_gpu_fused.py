@@ -161,7 +161,11 @@ def test_full_size_properties(gpu_ctx):
     (50, 33, 4, 64, 5, 1, 2, 30, 0),
     (45, 70, 1, 100, 4, -1, 1, 1000, 1),     # even window: generic passes
     (40, 20, 1, 260, 9, 1, 1, 7, 0),         # two 256-level chunks
-    (64, 36, 1, 128, 13, 1, 2, 1000, 1),     # static pass A, generic pass B
+    (64, 36, 1, 128, 13, 1, 2, 1000, 1),     # static windows beyond 11 (integer pass A)
+    (33, 47, 1, 64, 3, 1, 1, 9, 1),          # blocks of 9 rows for window 3
+    (40, 31, 1, 96, 5, -1, 1, 1000, 1),      # blocks of 10 rows for window 5
+    (48, 19, 1, 68, 17, 1, 1, 12, 0),
+    (30, 52, 4, 40, 15, 1, 2, 40, 0),
 ])
 def test_fused_box_dsi(gpu_ctx, oracle, w, h, b, D, win, sign, fn, mmax, interval):
     """smhip_fused_box_dsi == smhip_raw_costs + smhip_box_filter (== oracle), whole DSI, bit for
@@ -274,7 +278,7 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     kw = dict(disp_max=D - 1, frame_ref=fr, frame_match=fm, match_fn=1, match_max=4, match_interval=1,
               aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    for paired in (1, 0):            # columns in pairs (one band, windows 5..11; forced: the library pairs from 3584 columns on) / one column per wave
+    for paired in (1, 0):            # columns in pairs (one band, windows 3..11; forced: the library pairs from 3584 columns on) / one column per wave
         for keybuf in (-1, 0, 1):
             with gpu_ctx.options(keybuf=keybuf, paired=paired):
                 m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
@@ -282,6 +286,29 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
             assert m.used_fused
             assert np.array_equal(disp, odisp), (paired, keybuf)
             util.assert_bit_equal(best, obest, "best cost (paired %d, keybuf %d)" % (paired, keybuf))
+
+
+@pytest.mark.parametrize("win", [3, 5, 13, 15, 17])
+@pytest.mark.parametrize("D", [40, 100, 200, 300])
+def test_pass_b_blocks_of_other_windows(gpu_ctx, oracle, win, D):
+    """Pass B's static windows whose blocks are not one window long (3 and 5: blocks of 9 and 10 rows, the leaving
+    row comes from this block or the one before) and the wide ones (13..17: two waves per SIMD): heights of one
+    window, one block more or less, several key groups; 1, 2 and 4 levels per lane and two chunks."""
+    blk = {3: 9, 5: 10}.get(win, win)
+    for h in (win, win + 1, blk - 1, blk + 1, 2 * blk, 3 * blk + 2, 131):
+        if h < win:
+            continue
+        w = 24 + (h % 5)
+        left, right = synth.noise_pair(w, h, 1, seed=win * 100 + h)
+        kw = dict(disp_max=D - 1, match_fn=1, match_max=6, match_interval=1, aggr_window_size=win)
+        odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
+        for keybuf in (-1, 0):
+            with gpu_ctx.options(keybuf=keybuf):
+                m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
+                disp, best, _ = m.ComputeCorrespondence(left, right)
+            assert m.used_fused
+            assert np.array_equal(disp, odisp), (h, keybuf)
+            util.assert_bit_equal(best, obest, "best cost (h %d, keybuf %d)" % (h, keybuf))
 
 
 @pytest.mark.parametrize("w,h,D,win", [(70, 40, 256, 9), (41, 33, 128, 9), (300, 21, 500, 7), (64, 140, 200, 5)])
