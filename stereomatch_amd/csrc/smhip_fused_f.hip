@@ -31,10 +31,13 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
     // every workgroup at once (scripts/exp_occupancy*.sh, profiles/r02_occupancy.log): one-wave workgroups
     // (128-level slabs) 6 per CU -- 8K 3.11 -> 2.88 ms, 4K 0.848 -> 0.795, 1080p unchanged; two-wave workgroups
     // 2 per CU from 1280 rows on -- 4K 1.44 -> 1.38 ms, 8K 5.63 -> 5.30 (0.80 of 8 TB/s, the write ceiling),
-    // but 1080 rows (two and a bit rounds of 512) 0.380 -> 0.419, hence the row bound.  lds_min < 0: this policy.
+    // but 1080 rows (two and a bit rounds of 512) 0.380 -> 0.419, hence the row bound; and only from 2560 columns on
+    // (below).  lds_min < 0: this policy.
     size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
     if (lds_min < 0)
-        lds_min = nw == 1 ? 26 * 1024 : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);   // (four chunks, 8K x 1024: 22.4 against 22.1 ms without)
+        lds_min = a.W < 2560 ? 0 : nw == 1 ? 26 * 1024 : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);
+    // (four chunks, 8K x 1024: 22.4 against 22.1 ms without.  Rows shorter than 2560 pixels lose under a bound:
+    // 2048x1536 3 %, 1280x1400 11 %, 800x1300x512 15 %, 640x4000x128 7 % -- profiles/r02_occupancy.log, last part.)
     if (lds < (size_t)lds_min) lds = (size_t)lds_min;
     dim3 grid((unsigned)a.H * (unsigned)(Dp / cw));        // row-major over (row, chunk)
     if (nw == 2 && WIN > 9 && a.H < 1280) {                // all rows resident: three waves per SIMD (see the kernel)
