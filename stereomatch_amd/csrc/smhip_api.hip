@@ -1487,7 +1487,10 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         int b_waves = ctx->opt[SMHIP_OPT_B_WAVES] > 0 ? (ctx->opt[SMHIP_OPT_B_WAVES] + 1) & ~1 : 0;
         const bool b_policy = ctx->opt[SMHIP_OPT_B_WAVES] < 0;
         auto two_per_cu = [](long b) { return b > 64 && (b % 64 == 0 || b % 64 >= 38); };
-        if (b_policy && !keep_all && CH == 256 && two_per_cu((long)((x_per_xcd + wpb_policy - 1) / wpb_policy) * b_chunks))
+        const long b_per_xcd = (long)((x_per_xcd + wpb_policy - 1) / wpb_policy) * b_chunks;
+        // (with more than two chunks only up to two rounds: 1920x1080x1024, b = 240 in four chunks, is 3 % slower under
+        // the bound and 960x540x2048, eight chunks, 14 %, while 1000x1500x1024 and 1280x720x768, b = 128 / 120, gain 9 %)
+        if (b_policy && !keep_all && CH == 256 && two_per_cu(b_per_xcd) && (b_chunks <= 2 || b_per_xcd <= 128))
             b_waves = 8;
         const int wpb = (b_waves % 4) ? 2 : 4;
         dim3 gb(8 * ((x_per_xcd + wpb - 1) / wpb), b_chunks);
