@@ -120,6 +120,14 @@ def test_random_slab_partition(gpu_ctx, oracle, seed):
     sign = int(r.choice([0, 1]))
     kw = dict(match_fn=int(r.choice([1, 2])), match_interval=int(r.rand() < 0.6),
               match_max=int(r.choice([1000, 20, 2])))
+    # launch-shape knobs drawn last, so that the shapes of the earlier seeds stay what they were
+    r2 = np.random.RandomState(77000 + seed)
+    if r2.rand() < 0.3:
+        win = int(r2.choice([13, 15, 17]))
+        h = max(h, win)
+        w = max(w, win)
+    opts = dict(paired=int(r2.choice([-1, 0, 1])), a_lds_kb=int(r2.choice([-1, 0, 26, 54])),
+                b_waves=int(r2.choice([-1, 0, 6, 8, 12])), keybuf=int(r2.choice([-1, -1, 0, 1, 3])))
     seq = dict(disp_min=0, disp_max=D - 1)
     if sign:
         seq.update(frame_ref=1, frame_match=0)
@@ -132,12 +140,13 @@ def test_random_slab_partition(gpu_ctx, oracle, seed):
     cuts = sorted(set([0, D] + [int(x) for x in r.randint(1, D, size=n_slabs - 1)]))
     keys = gpu_ctx.alloc(w * h * 8)
     merged = None
-    for lo, hi in zip(cuts[:-1], cuts[1:]):
-        gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, w * b, p, win, lo, hi - lo, keys)
-        k = gpu_ctx.download(keys, (w, h), np.int64)
-        merged = k if merged is None else np.minimum(merged, k)
+    with gpu_ctx.options(**opts):
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            gpu_ctx.fused_box_wta_keys(d_ref, d_mtc, w * b, p, win, lo, hi - lo, keys)
+            k = gpu_ctx.download(keys, (w, h), np.int64)
+            merged = k if merged is None else np.minimum(merged, k)
     d, c = sharding.decode_keys(merged)
-    assert np.array_equal(d.T, odisp), (seed, cuts)
+    assert np.array_equal(d.T, odisp), (seed, cuts, opts)
     util.assert_bit_equal(np.ascontiguousarray(c.T), obest, "best cost %s" % cuts)
 
 
