@@ -4,9 +4,12 @@ python -c "
 import json; d=json.load(open('gpurun_out/b.json')); print('$*', d['value'], d['ms_per_step'], [(k['kernel'][:16], k['avg_ms'], k['frac']) for k in d['kernels']], d['roofline_fused']['frac'])"; }
 mkdir -p gpurun_out
 run &&
+run --window 3 &&
 run --window 5 &&
 run --window 7 &&
 run --window 11 &&
+run --window 13 &&
+run --window 15 &&
 run --window 17 &&
 run --bands 4 &&
 run --width 3840 --height 2160 --disp-total 512 &&
