@@ -181,7 +181,7 @@ def _ptr(x):
 
 
 # enum smhip_option (include/smhip.h)
-OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12}
+OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13}
 
 
 class Context:

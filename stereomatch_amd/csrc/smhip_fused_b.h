@@ -57,7 +57,7 @@ __device__ __forceinline__ void load_row(const float *p, float (&v)[VPL])
 // unpaired 128-level slab is read with 512-byte loads, whose ceiling is 0.68 instead of 0.86 of 8 TB/s,
 // scripts/membw8.hip), the two columns are independent (no exchange between the half-waves), and one DPP
 // reduction over each half-wave serves two pixels.  W, H stay the image's; Dp must be 128.
-template <int WIN, int VPL, int ABL = 0, bool STORE = false, bool PAIR = false>   // ABL: ablation switches of scripts/bench_b.hip (0 = product)
+template <int WIN, int VPL, int ABL = 0, bool STORE = false, bool PAIR = false, int AHEAD = 1>   // ABL: ablation switches of scripts/bench_b.hip (0 = product); AHEAD: blocks of rolling prefetch
 __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
@@ -249,7 +249,40 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
         }
     };
 
-    if (WIN) {
+    if (WIN && AHEAD == 2) {                           // prefetch two blocks ahead (four register blocks): VPL 1 and 2
+        float b0[BLK][VPL], b1[BLK][VPL], b2[BLK][VPL], b3[BLK][VPL];
+#pragma unroll
+        for (int r = 0; r < BLK; r++) {
+            if (r < WIN)
+                ld(r + pl, b0[OFF + r]);
+            ld(r + pr, b1[r]);
+            ld(BLK + r + pr, b2[r]);
+        }
+#pragma unroll
+        for (int i = 0; i < VPL; i++)
+            b0[OFF][i] = b1[0][i];
+        auto block = [&](float(&prv)[BLK][VPL], float(&cur)[BLK][VPL], float(&nxt)[BLK][VPL], int yb) {
+            const int slot0 = yb % GRP;
+#pragma unroll
+            for (int r = 0; r < BLK; r++) {
+                ld(yb + 2 * BLK + r + pr, nxt[r]);
+                if (r >= WIN)
+                    step(cur[r - (r >= WIN ? WIN : 0)], cur[r], slot0 + r, yb + r);
+                else
+                    step(prv[OFF + r], cur[r], slot0 + r, yb + r);
+            }
+            flush(yb);
+        };
+        for (int yb = 0; yb < H; yb += 4 * BLK) {
+            block(b0, b1, b3, yb);
+            if (yb + BLK < H)
+                block(b1, b2, b0, yb + BLK);
+            if (yb + 2 * BLK < H)
+                block(b2, b3, b1, yb + 2 * BLK);
+            if (yb + 3 * BLK < H)
+                block(b3, b0, b2, yb + 3 * BLK);
+        }
+    } else if (WIN) {
         float b0[BLK][VPL], b1[BLK][VPL], b2[BLK][VPL];
 #pragma unroll
         for (int r = 0; r < BLK; r++) {

@@ -288,7 +288,7 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
             util.assert_bit_equal(best, obest, "best cost (paired %d, keybuf %d)" % (paired, keybuf))
 
 
-@pytest.mark.parametrize("win", [3, 5, 13, 15, 17])
+@pytest.mark.parametrize("win", [3, 5, 9, 13, 15, 17])
 @pytest.mark.parametrize("D", [40, 100, 200, 300])
 def test_pass_b_blocks_of_other_windows(gpu_ctx, oracle, win, D):
     """Pass B's static windows whose blocks are not one window long (3 and 5: blocks of 9 and 10 rows, the leaving
@@ -302,13 +302,13 @@ def test_pass_b_blocks_of_other_windows(gpu_ctx, oracle, win, D):
         left, right = synth.noise_pair(w, h, 1, seed=win * 100 + h)
         kw = dict(disp_max=D - 1, match_fn=1, match_max=6, match_interval=1, aggr_window_size=win)
         odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-        for keybuf in (-1, 0):
-            with gpu_ctx.options(keybuf=keybuf):
+        for keybuf, ahead in ((-1, -1), (0, -1), (-1, 1)):       # (ahead: levels <= 128 prefetch two blocks / one)
+            with gpu_ctx.options(keybuf=keybuf, b_ahead=ahead):
                 m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
                 disp, best, _ = m.ComputeCorrespondence(left, right)
             assert m.used_fused
-            assert np.array_equal(disp, odisp), (h, keybuf)
-            util.assert_bit_equal(best, obest, "best cost (h %d, keybuf %d)" % (h, keybuf))
+            assert np.array_equal(disp, odisp), (h, keybuf, ahead)
+            util.assert_bit_equal(best, obest, "best cost (h %d, keybuf %d, ahead %d)" % (h, keybuf, ahead))
 
 
 @pytest.mark.parametrize("w,h,D,win", [(70, 40, 256, 9), (41, 33, 128, 9), (300, 21, 500, 7), (64, 140, 200, 5)])
@@ -319,7 +319,8 @@ def test_occupancy_options(gpu_ctx, oracle, w, h, D, win):
     kw = dict(disp_max=D - 1, match_fn=1, match_max=5, match_interval=1, aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
     for opts in (dict(a_lds_kb=0, b_waves=0), dict(a_lds_kb=54, b_waves=8), dict(a_lds_kb=26, b_waves=6),
-                 dict(a_lds_kb=80, b_waves=16), dict(b_waves=10, keybuf=2), dict(a_lds_kb=41, paired=1)):
+                 dict(a_lds_kb=80, b_waves=16), dict(b_waves=10, keybuf=2), dict(a_lds_kb=41, paired=1),
+                 dict(b_ahead=1), dict(b_ahead=2, paired=0)):
         with gpu_ctx.options(**opts):
             m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
             disp, best, _ = m.ComputeCorrespondence(left, right)
