@@ -17,25 +17,28 @@ ap.add_argument("--levels", type=int, default=256)
 ap.add_argument("--total", type=int, default=0)
 ap.add_argument("--first", type=int, default=0)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--bands", type=int, default=1)
+ap.add_argument("--window", type=int, default=9)
 ap.add_argument("--opts", nargs="+", default=["{}", '{"float_a": 0}'], help="option sets as JSON objects")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.levels
 D = args.total or n
 dev = torch.device("cuda", 0)
-left, right, _ = synth.scene_pair(W, H, 256)
+nb = args.bands
+left, right, _ = synth.scene_pair(W, H, 256, n_bands=nb)
 ctx = capi.Context(0)
 stream = torch.cuda.Stream(device=dev)
 torch.cuda.set_stream(stream)
 ctx.set_stream(stream.cuda_stream)
-t_ref, t_mtc = torch.from_numpy(left.reshape(H, W)).to(dev), torch.from_numpy(right.reshape(H, W)).to(dev)
+t_ref, t_mtc = torch.from_numpy(left.reshape(H, W * nb)).to(dev), torch.from_numpy(right.reshape(H, W * nb)).to(dev)
 keys = torch.empty((W, H), dtype=torch.int64, device=dev)
 disp = torch.empty((H, W), dtype=torch.int32, device=dev)
 best = torch.empty((H, W), dtype=torch.float32, device=dev)
-p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1, match_max=1000)
+p = capi.match_params(W, H, nb, D, match_fn=1, match_interval=1, match_max=1000)
 
 
 def step():
-    ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W, p, 9, args.first, n, keys.data_ptr())
+    ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * nb, p, args.window, args.first, n, keys.data_ptr())
     ctx.keys_decode(keys.data_ptr(), W, H, disp.data_ptr(), best.data_ptr())
 
 
