@@ -357,6 +357,44 @@ def evaluate(fdisp, truth, ref, p, verbose_summary=True, **kw):
     return res
 
 
+def evaluate_masks(fdisp, truth, ref, p, **kw):
+    """(m_occlusion, m_textureless) of the evaluation, [H, W] uint8 each."""
+    e = Eval(ignore_border=0, bad_thresh=1.0, disp_gap=2.0, textureless_width=3,
+             textureless_thresh=4.0, discont_width=9)
+    for k, v in kw.items():
+        if not hasattr(e, k):
+            raise KeyError(k)
+        setattr(e, k, v)
+    ref = _img(ref)
+    h, w, b = ref.shape
+    fd = np.ascontiguousarray(fdisp, np.float32)
+    tr = np.ascontiguousarray(truth, np.uint8).reshape(h, w)
+    occ, texl = np.empty((h, w), np.uint8), np.empty((h, w), np.uint8)
+    L = lib()
+    L.smo_evaluate_masks.restype = None
+    L.smo_evaluate_masks.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.c_long,
+                                     C.POINTER(Params), C.POINTER(Eval), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]
+    L.smo_evaluate_masks(_fp(fd), _u8(tr), _u8(ref), w * b, C.byref(p), C.byref(e), _u8(occ), _u8(texl))
+    return occ, texl
+
+
+def cost_histogram(img, mask, v_scale=0.0, min_val=0.0, max_val=32.0, n_bins=256, height=256):
+    """Histogram1D figure of ComputeMatchQuality (StcEvaluate.cpp:848-861): returns (figure [height, n_bins]
+    uint8, the vertical scale used)."""
+    img = np.ascontiguousarray(img, np.float32)
+    h, w = img.shape
+    fig = np.empty((height, n_bins), np.uint8)
+    vs = C.c_float(v_scale)
+    L = lib()
+    L.smo_cost_histogram.restype = None
+    L.smo_cost_histogram.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_int, C.c_int, C.c_float,
+                                     C.c_float, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint8)]
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    L.smo_cost_histogram(_fp(img), None if m is None else _u8(m), w, h, min_val, max_val, n_bins, height,
+                         C.byref(vs), _u8(fig))
+    return fig, vs.value
+
+
 class Predict(C.Structure):
     """smo_predict with the defaults of StereoParameters.cpp:104-113."""
     _fields_ = [("predict_type", C.c_int), ("lin_interp", C.c_int), ("disp_gap", C.c_float),

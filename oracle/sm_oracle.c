@@ -933,8 +933,9 @@ static void forward_warp_row(const void *src, void *dst, const float *dp, int w,
     }
 }
 
-void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
-                  const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out)
+static void evaluate_impl(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                          const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out,
+                          uint8_t *occ_out, uint8_t *texl_out)
 {
     int w = p->width, h = p->height, nB = p->n_bands;
     size_t n = (size_t)w * h;
@@ -1056,7 +1057,59 @@ void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, 
     }
     if (verbose_summary)
         out->fraction_matched *= 0.1f;               /* :583 */
+    if (occ_out) memcpy(occ_out, occ, n);
+    if (texl_out) memcpy(texl_out, texl, n);
     free(trud); free(fwd); free(white); free(occ); free(texl); free(disc); free(sq); free(tmp); free(dd);
+}
+
+void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                  const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out)
+{
+    evaluate_impl(fdisp, truth, ref, img_row_bytes, p, e, verbose_summary, out, NULL, NULL);
+}
+
+/* the same evaluation, also handing out m_occlusion (255 = occluded or border) and m_textureless */
+void smo_evaluate_masks(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                        const smo_params *p, const smo_eval *e, uint8_t *occlusion, uint8_t *textureless)
+{
+    smo_eval_out out;
+    evaluate_impl(fdisp, truth, ref, img_row_bytes, p, e, 0, &out, occlusion, textureless);
+}
+
+/* Histogram1D drawn as a figure (Histogram1D.cpp:32-139) for the arguments ComputeMatchQuality gives it
+ * (StcEvaluate.cpp:848-861): one-band float image, fixed value range, n_bins > 0, height > 0.  mask may be NULL;
+ * the first zero of the mask ends the scan of its row (:86-87 `break`).  *v_scale <= 0: found from the tallest
+ * bin and handed back (:118-119, :855).  figure: n_bins x height bytes. */
+void smo_cost_histogram(const float *img, const uint8_t *mask, int w, int h, float min_val, float max_val,
+                        int n_bins, int height, float *v_scale, uint8_t *figure)
+{
+    float step_size = (max_val - min_val) / (float)n_bins;
+    float inv_step_size = 1.0f / step_size;
+    int *counts = calloc((size_t)n_bins, sizeof(int));
+    for (int y = 0; y < h; y++) {
+        const float *q = img + (size_t)y * w;
+        const uint8_t *m = mask ? mask + (size_t)y * w : NULL;
+        for (int x = 0; x < w; x++) {
+            if (m && m[x] == 0)
+                break;
+            int bin = (int)((q[x] - min_val) * inv_step_size);
+            bin = imin(imax(0, bin), n_bins - 1);
+            counts[bin] += 1;
+        }
+    }
+    int max_count = 0;
+    for (int i = 0; i < n_bins; i++)
+        max_count = imax(max_count, counts[i]);
+    if (*v_scale <= 0)
+        *v_scale = height / (float)max_count;
+    for (int i = 0; i < n_bins; i++)
+        counts[i] = imin(height - 1, (int)(counts[i] * *v_scale + 0.5));
+    for (int y = 0; y < height; y++) {
+        int y2 = height - 1 - y;
+        for (int x = 0; x < n_bins; x++)
+            figure[(size_t)y * n_bins + x] = (y2 >= counts[x]) ? 255 : 0;
+    }
+    free(counts);
 }
 
 /* ------------------------------------------------------------------------- */

@@ -156,6 +156,13 @@ typedef struct smo_eval_out {
 } smo_eval_out;
 void smo_evaluate(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
                   const smo_params *p, const smo_eval *e, int verbose_summary, smo_eval_out *out);
+/* the same evaluation, handing out m_occlusion and m_textureless (w x h bytes each) */
+void smo_evaluate_masks(const float *fdisp, const uint8_t *truth, const uint8_t *ref, long img_row_bytes,
+                        const smo_params *p, const smo_eval *e, uint8_t *occlusion, uint8_t *textureless);
+/* Histogram1D as ComputeMatchQuality draws it (Histogram1D.cpp:32-139, StcEvaluate.cpp:848-861): parity
+ * unpinned (the reference holds no such figure) */
+void smo_cost_histogram(const float *img, const uint8_t *mask, int w, int h, float min_val, float max_val,
+                        int n_bins, int height, float *v_scale, uint8_t *figure);
 
 /* Prediction (re-projection) error of one frame (ComputePredictionErrors, StcEvaluate.cpp:588-758;
  * ForwardWarp / InverseWarp, Warp1D.cpp:25-257).  ref = the un-preprocessed reference image, frame =

@@ -9,6 +9,9 @@
 // predict_err_* and the frames' resampled images.  Not restated: match quality (:760-863) and the
 // status statistics (:865-954; WTA leaves no status map).
 #include "StereoMatcher.h"
+#include <algorithm>
+#include <vector>
+
 #include "ImageIO.h"
 #include "Error.h"
 #include <cmath>
@@ -453,7 +456,46 @@ void CStereoMatcher::ComputePredictionErrors()
 // ComputeMatchQuality (StcEvaluate.cpp:760-863): cost and certainty at the winner, computed by
 // smhip_match_quality on the DSI that is still resident on the device; with verbose >= eVerboseDumpFiles
 // the two images go to reprojected/final_cost.pgm (x16) and reprojected/certainty.pgm (x0.5) as in
-// :836-846.  The cost histograms of :848-861 are not drawn.
+// :836-846, and the three cost histograms of :848-861 follow (all pixels, occluded, textureless).
+
+// Histogram of a one-band float image drawn as a figure of n_bins x height pixels (the reference's Histogram1D,
+// Histogram1D.cpp:32-139, for the arguments ComputeMatchQuality gives it: fixed value range, n_bins > 0,
+// height > 0).  A mask of the image's size restricts the count -- and, as there, the first zero of the mask ends
+// the scan of its ROW (Histogram1D.cpp:86-87 leaves the loop over x), it does not skip one pixel.  v_scale <= 0:
+// the tallest bin fills the height, and the scale found is handed back for the next call (:855).
+static void DrawCostHistogram(const CFloatImage &img, const CByteImage &mask, CByteImage &figure, float min_val,
+                              float max_val, int n_bins, int height, float &v_scale)
+{
+    const CShape sh = img.Shape(), msh = mask.Shape();
+    const bool valid_mask = sh.width == msh.width && sh.height == msh.height;
+    const float step_size = (max_val - min_val) / (float)n_bins;           // Histogram1D.cpp:69-70
+    const float inv_step_size = 1.0f / step_size;
+    std::vector<int> counts((size_t)n_bins, 0);
+    for (int y = 0; y < sh.height; y++) {
+        const float *p = img.Row(y);
+        const uchar *m = valid_mask ? mask.Row(y) : nullptr;
+        for (int x = 0; x < sh.width; x++) {
+            if (m && m[x] == 0)
+                break;
+            int bin = (int)((p[x] - min_val) * inv_step_size);
+            bin = std::min(std::max(0, bin), n_bins - 1);
+            counts[(size_t)bin] += 1;
+        }
+    }
+    const int max_count = *std::max_element(counts.begin(), counts.end());
+    if (v_scale <= 0)
+        v_scale = height / (float)max_count;                                // Histogram1D.cpp:118-119
+    figure.ReAllocate(CShape(n_bins, height, 1));
+    for (int y = 0; y < height; y++) {
+        uchar *row = figure.Row(y);
+        const int y2 = height - 1 - y;
+        for (int x = 0; x < n_bins; x++) {
+            const int c = std::min(height - 1, (int)(counts[(size_t)x] * v_scale + 0.5));
+            row[x] = y2 >= c ? 255 : 0;
+        }
+    }
+}
+
 void CStereoMatcher::ComputeMatchQuality()
 {
     if (m_used_fused || m_keys_done || !m_dev[B_COST])
@@ -493,6 +535,17 @@ void CStereoMatcher::ComputeMatchQuality()
             }
         }
         WriteImage(fc, d.name);
+    }
+    // :848-861 -- cost range [0, 32) in 256 bins, 256 rows; the first figure's vertical scale serves all three
+    float vscale = 0.0f;
+    const struct { const CByteImage *mask; const char *name; } hists[] = {
+        {nullptr, "reprojected/final_cost_hist_all.pgm"},
+        {&m_occlusion, "reprojected/final_cost_hist_occluded.pgm"},
+        {&m_textureless, "reprojected/final_cost_hist_textureless.pgm"}};
+    const CByteImage no_mask;
+    for (const auto &hst : hists) {
+        DrawCostHistogram(m_final_cost, hst.mask ? *hst.mask : no_mask, fc, 0.0f, 32.0f, 256, 256, vscale);
+        WriteImage(fc, hst.name);
     }
 }
 
