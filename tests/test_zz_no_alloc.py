@@ -46,6 +46,22 @@ def test_noalloc_equals_allocating_entry_point():
         ctx.close()
 
 
+def test_noalloc_with_paired_columns_and_bounded_occupancy():
+    """The launch shapes added late in round 2 inside the no-allocation call: a 128-level slab with its columns in
+    pairs (an odd width: the slab is one column wider than the unpaired one) and the LDS floors of both passes."""
+    ctx = capi.Context(0)
+    try:
+        with ctx.options(paired=1, a_lds_kb=26, b_waves=8):
+            run_both(ctx, 151, 60, 1, 128, 9, match_fn=1, match_interval=1, match_max=30)
+            run_both(ctx, 90, 40, 1, 100, 5, match_fn=2, match_max=1000)
+        with ctx.options(a_lds_kb=54, b_waves=8):
+            run_both(ctx, 120, 50, 1, 256, 9, match_fn=1, match_interval=1)
+        ctx.sync()
+        assert ctx.workspace_bytes() > 0       # (run_both's allocating call grew it; the next test checks the other side)
+    finally:
+        ctx.close()
+
+
 def test_noalloc_grows_no_workspace():
     ctx = capi.Context(0)
     try:
