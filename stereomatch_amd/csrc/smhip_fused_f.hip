@@ -35,7 +35,17 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
     // (below).  lds_min < 0: this policy.
     size_t lds = (size_t)nmatch * 8 + (size_t)nref * 4;
     if (lds_min < 0)
-        lds_min = a.W < 2560 ? 0 : nw == 1 ? 26 * 1024 : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);
+    {
+        // one-wave workgroups: five or six per CU (31 / 26 KB), whichever fills its rounds better -- 4K x 128 (2160
+        // rows): 0.794 ms at six (two rounds of 1536, 0.70 full), 0.746 at five (two of 1280, 0.84); 5120x2880: 1.293
+        // at six (0.94) against 1.334 at five (0.75); 8K: 2.897 / 2.893 (0.94 / 0.84)
+        auto fill = [&](long per_cu) {
+            const long slots = 256 * per_cu, wgs = (long)a.H * (Dp / cw);
+            return (double)wgs / (double)((wgs + slots - 1) / slots * slots);
+        };
+        const long one_wave = fill(5) > fill(6) + 0.05 ? 31 * 1024 : 26 * 1024;
+        lds_min = a.W < 2560 ? 0 : nw == 1 ? one_wave : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);
+    }
     // (four chunks, 8K x 1024: 22.4 against 22.1 ms without.  Rows shorter than 2560 pixels lose under a bound:
     // 2048x1536 3 %, 1280x1400 11 %, 800x1300x512 15 %, 640x4000x128 7 % -- profiles/r02_occupancy.log, last part.)
     if (lds < (size_t)lds_min) lds = (size_t)lds_min;
