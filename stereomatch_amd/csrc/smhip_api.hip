@@ -1505,7 +1505,10 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (kb_groups > 64) kb_groups = 64;                 // 4 waves x 64 groups x 64 rows x 8 B = 128 KB
         const int kb_rows = kgrp * kb_groups;
         size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long);
-        const size_t b_lds_min = b_waves ? (size_t)(163840 / (b_waves / wpb)) & ~(size_t)255 : 0;   // 160 KB of LDS per CU
+        // 160 KB of LDS per CU, the exact share.  (Asking for 4 KB less -- 76 instead of 80 KB, still two workgroups
+        // per CU -- measured 1.44 instead of 1.29 ms at 3840x2160x256: unexplained, so the share stays exact; a third
+        // of 160 KB, 53.25 KB, gives two per CU, not three.)
+        const size_t b_lds_min = b_waves ? (size_t)(163840 / (b_waves / wpb)) & ~(size_t)255 : 0;
         if (kb_lds < b_lds_min) kb_lds = b_lds_min;
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
