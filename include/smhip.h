@@ -83,7 +83,7 @@ enum smhip_option {
     SMHIP_OPT_A_LDS_KB,       /* least LDS per workgroup of the float-lane pass A, KiB (<= 80): bounds the workgroups per CU; 0 none */
     SMHIP_OPT_B_WAVES,        /* pass B waves resident per CU, 6..16 (even; bounded through the LDS a workgroup asks for); 0 no bound */
     SMHIP_OPT_STAGE_LDS_KB,   /* LDS floor of the stage kernels, KiB, 0..80 (bounds the workgroups per CU) */
-    SMHIP_OPT_B_AHEAD,        /* 2 / 1: pass B of slabs up to 128 levels prefetches two blocks of rows ahead / one */
+    SMHIP_OPT_B_AHEAD,        /* pass B of slabs up to 128 levels: 1 = one block of rows in flight, 2 = two; default two, four on up to 2048 columns */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);

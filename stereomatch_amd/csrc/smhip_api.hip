@@ -1513,17 +1513,22 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
         d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
-#define LAUNCH_BT2(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL, 0, false, false, 2><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
+#define LAUNCH_BT2(WIN, VPL) LAUNCH_BTA(WIN, VPL, 2)
+#define LAUNCH_BT4(WIN, VPL) LAUNCH_BTA(WIN, VPL, (WIN <= 11 ? 4 : 2))
+#define LAUNCH_BTA(WIN, VPL, AH) smk::fused_boxv_wta_vpl_kernel<WIN, VPL, 0, false, false, AH><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
         d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
         // slabs of up to 128 levels (256- / 512-byte rows per wave): two blocks of rows in flight instead of one,
         // 3-4 % faster from 1280x720 to 3840x2160 (one block of nine such rows per wave is less than the memory's
         // latency x bandwidth); 256-level waves gain nothing from it (0.335 against 0.331 ms).  SMHIP_OPT_B_AHEAD = 1: off
         const bool ahead2 = ctx->opt[SMHIP_OPT_B_AHEAD] != 1;
+        // ... and four blocks where few waves walk (up to 2048 columns; windows up to 11): 1920x1080x128 0.252 -> 0.244
+        // (two) -> 0.239 ms (four), x64 0.213 -> 0.196, 1280x720x128 0.170 -> 0.160; 3072 columns: 0.470 / 0.471 / 0.478
+        const bool ahead4 = ahead2 && (long)W * n_chunks <= 2048 && ctx->opt[SMHIP_OPT_B_AHEAD] != 2;
 #define LAUNCH_BW(WIN)                                 \
         switch (CH / 64) {                             \
-        case 1: if (ahead2 && WIN) LAUNCH_BT2(WIN, 1); else LAUNCH_BT(WIN, 1); break;              \
-        case 2: if (ahead2 && WIN) LAUNCH_BT2(WIN, 2); else LAUNCH_BT(WIN, 2); break;              \
+        case 1: if (ahead4 && WIN) LAUNCH_BT4(WIN, 1); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 1); else LAUNCH_BT(WIN, 1); break; \
+        case 2: if (ahead4 && WIN) LAUNCH_BT4(WIN, 2); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 2); else LAUNCH_BT(WIN, 2); break; \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
         if (paired) {                // (the float-lane pass A ran: window 3 .. 11, Dp 128, keys out)
@@ -1577,7 +1582,9 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 #undef LAUNCH_BS
         }
 #undef LAUNCH_BW
+#undef LAUNCH_BT4
 #undef LAUNCH_BT2
+#undef LAUNCH_BTA
 #undef LAUNCH_BT
     } else {
         int pix_per_blk = 256 / CH;

@@ -249,23 +249,25 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
         }
     };
 
-    if (WIN && AHEAD == 2) {                           // prefetch two blocks ahead (four register blocks): VPL 1 and 2
-        float b0[BLK][VPL], b1[BLK][VPL], b2[BLK][VPL], b3[BLK][VPL];
+    if (WIN && AHEAD >= 2) {                           // prefetch AHEAD blocks ahead (AHEAD + 2 register blocks): VPL 1 and 2
+        constexpr int NBUF = AHEAD + 2;
+        float bb[NBUF][BLK][VPL];                      // (every index below is a constant after unrolling)
 #pragma unroll
         for (int r = 0; r < BLK; r++) {
             if (r < WIN)
-                ld(r + pl, b0[OFF + r]);
-            ld(r + pr, b1[r]);
-            ld(BLK + r + pr, b2[r]);
+                ld(r + pl, bb[0][OFF + r]);
+#pragma unroll
+            for (int a = 0; a < AHEAD; a++)
+                ld(a * BLK + r + pr, bb[1 + a][r]);
         }
 #pragma unroll
         for (int i = 0; i < VPL; i++)
-            b0[OFF][i] = b1[0][i];
+            bb[0][OFF][i] = bb[1][0][i];
         auto block = [&](float(&prv)[BLK][VPL], float(&cur)[BLK][VPL], float(&nxt)[BLK][VPL], int yb) {
             const int slot0 = yb % GRP;
 #pragma unroll
             for (int r = 0; r < BLK; r++) {
-                ld(yb + 2 * BLK + r + pr, nxt[r]);
+                ld(yb + AHEAD * BLK + r + pr, nxt[r]);
                 if (r >= WIN)
                     step(cur[r - (r >= WIN ? WIN : 0)], cur[r], slot0 + r, yb + r);
                 else
@@ -273,14 +275,11 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
             }
             flush(yb);
         };
-        for (int yb = 0; yb < H; yb += 4 * BLK) {
-            block(b0, b1, b3, yb);
-            if (yb + BLK < H)
-                block(b1, b2, b0, yb + BLK);
-            if (yb + 2 * BLK < H)
-                block(b2, b3, b1, yb + 2 * BLK);
-            if (yb + 3 * BLK < H)
-                block(b3, b0, b2, yb + 3 * BLK);
+        for (int yb = 0; yb < H; yb += NBUF * BLK) {
+#pragma unroll
+            for (int k = 0; k < NBUF; k++)
+                if (yb + k * BLK < H)                  // block k: rows in bb[k] | bb[k + 1], loads into bb[k + AHEAD + 1]
+                    block(bb[k], bb[(k + 1) % NBUF], bb[(k + AHEAD + 1) % NBUF], yb + k * BLK);
         }
     } else if (WIN) {
         float b0[BLK][VPL], b1[BLK][VPL], b2[BLK][VPL];

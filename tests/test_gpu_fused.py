@@ -302,7 +302,7 @@ def test_pass_b_blocks_of_other_windows(gpu_ctx, oracle, win, D):
         left, right = synth.noise_pair(w, h, 1, seed=win * 100 + h)
         kw = dict(disp_max=D - 1, match_fn=1, match_max=6, match_interval=1, aggr_window_size=win)
         odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-        for keybuf, ahead in ((-1, -1), (0, -1), (-1, 1)):       # (ahead: levels <= 128 prefetch two blocks / one)
+        for keybuf, ahead in ((-1, -1), (0, -1), (-1, 1), (-1, 2)):   # (ahead: levels <= 128 keep four / one / two blocks of rows in flight)
             with gpu_ctx.options(keybuf=keybuf, b_ahead=ahead):
                 m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
                 disp, best, _ = m.ComputeCorrespondence(left, right)
