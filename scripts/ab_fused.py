@@ -19,6 +19,7 @@ ap.add_argument("--first", type=int, default=0)
 ap.add_argument("--steps", type=int, default=30)
 ap.add_argument("--bands", type=int, default=1)
 ap.add_argument("--window", type=int, default=9)
+ap.add_argument("--interval", type=int, default=1)
 ap.add_argument("--opts", nargs="+", default=["{}", '{"float_a": 0}'], help="option sets as JSON objects")
 args = ap.parse_args()
 W, H, n = args.width, args.height, args.levels
@@ -34,7 +35,7 @@ t_ref, t_mtc = torch.from_numpy(left.reshape(H, W * nb)).to(dev), torch.from_num
 keys = torch.empty((W, H), dtype=torch.int64, device=dev)
 disp = torch.empty((H, W), dtype=torch.int32, device=dev)
 best = torch.empty((H, W), dtype=torch.float32, device=dev)
-p = capi.match_params(W, H, nb, D, match_fn=1, match_interval=1, match_max=1000)
+p = capi.match_params(W, H, nb, D, match_fn=1, match_interval=args.interval, match_max=1000)
 
 
 def step():

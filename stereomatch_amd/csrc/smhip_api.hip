@@ -505,8 +505,14 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
             if (a.sd) smk::raw_costs_rows_kernel<true, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
             else      smk::raw_costs_rows_kernel<false, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
         } else {
-            if (a.sd) smk::raw_costs_rows_kernel<true, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
-            else      smk::raw_costs_rows_kernel<false, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            const bool pts = fa.rn == fa.rx && fa.mn == fa.mx;     // point intervals: RowLds<5>
+            if (pts) {
+                if (a.sd) smk::raw_costs_rows_kernel<true, 5><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+                else      smk::raw_costs_rows_kernel<false, 5><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            } else {
+                if (a.sd) smk::raw_costs_rows_kernel<true, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+                else      smk::raw_costs_rows_kernel<false, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            }
         }
     } else {
         smk::raw_costs_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(a, d_cost, row_elems);
@@ -1450,6 +1456,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
 #define LAUNCH_A(WIN)                                                             \
         do {                                                                      \
             if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
+            else if (fa.rn == fa.rx && fa.mn == fa.mx) { if (a.sd) LAUNCH_A3(WIN, true, 5); else LAUNCH_A3(WIN, false, 5); } \
             else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \
         } while (0)
         if (!float_a)

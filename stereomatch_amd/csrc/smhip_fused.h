@@ -95,6 +95,42 @@ template <> struct RowLds<4> {
     }
 };
 
+// NB = 5: four bands with POINT intervals on both sides (no Birchfield-Tomasi sampling): half the staged words,
+// and the SAD of a pixel pair is one v_sad_u8 instead of four interval distances (1920x1080x256, b = 4: pass A
+// 0.48 -> 0.43 ms; a run-time switch inside RowLds<4> cost the interval form 8 %, hence a type of its own)
+template <> struct RowLds<5> {
+    uint32_t *rn, *mn;
+    __device__ static size_t bytes(int W) { return (size_t)W * 8; }
+    __device__ void init(void *base, int W) { rn = (uint32_t *)base; mn = rn + W; }
+    __device__ void stage(const FusedA &a, size_t ro, int i) const
+    {
+        rn[i] = *(const uint32_t *)(a.rn + ro + 4 * (size_t)i);
+        mn[i] = *(const uint32_t *)(a.mn + ro + 4 * (size_t)i);
+    }
+    __device__ void init2(void *base, int nref, int) { rn = (uint32_t *)base; mn = rn + nref; }
+    __device__ void stage_r(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        rn[slot] = *(const uint32_t *)(a.rn + ro + 4 * (size_t)src);
+    }
+    __device__ void stage_m(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        mn[slot] = *(const uint32_t *)(a.mn + ro + 4 * (size_t)src);
+    }
+    template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
+    {
+        const uint32_t r = rn[xr], m = mn[xm];
+        if (!SD)
+            return (int)__builtin_amdgcn_sad_u8(r, m, 0u);
+        int sum = 0;
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            const int e = (int)((r >> s) & 0xFF) - (int)((m >> s) & 0xFF);
+            sum += e * e;
+        }
+        return sum;
+    }
+};
+
 template <int WIN, bool SD, int NB>
 __global__ __launch_bounds__(256) void fused_rawbox_h_lds_kernel(FusedA a, float *__restrict__ T,
                                                                  int tyshift, int Dp, int win,
