@@ -509,6 +509,8 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
             if (pts) {
                 if (a.sd) smk::raw_costs_rows_kernel<true, 5><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
                 else      smk::raw_costs_rows_kernel<false, 5><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            } else if (fa.rn == fa.rx && !a.sd) {                 // point reference, interval matching, SAD: RowLds<6>
+                smk::raw_costs_rows_kernel<false, 6><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
             } else {
                 if (a.sd) smk::raw_costs_rows_kernel<true, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
                 else      smk::raw_costs_rows_kernel<false, 4><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
@@ -1427,7 +1429,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (nref > W) nref = W;
         if (nmatch > W) nmatch = W;
         if (chunked)
-            lds = (size_t)(nref + nmatch) * (nbands == 1 ? 2 : 8);
+            lds = nbands == 1 ? (size_t)(nref + nmatch) * 2     // (four bands: RowLds<4> 8 + 8 bytes, RowLds<6> 4 + 12)
+                              : (size_t)nref * 8 + (size_t)nmatch * 12;
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "row staging needs %zu bytes of LDS (width %d, window %d, step %d)", lds, W,
                         window, adstep);
@@ -1457,6 +1460,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         do {                                                                      \
             if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
             else if (fa.rn == fa.rx && fa.mn == fa.mx) { if (a.sd) LAUNCH_A3(WIN, true, 5); else LAUNCH_A3(WIN, false, 5); } \
+            else if (fa.rn == fa.rx && !a.sd) LAUNCH_A3(WIN, false, 6); \
             else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \
         } while (0)
         if (!float_a)
