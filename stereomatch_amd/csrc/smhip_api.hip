@@ -489,7 +489,8 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
     const int nbands = p->n_bands, W = p->width, H = p->height;
     const bool img_ok = nbands == 1 || (img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 &&
                                         ((uintptr_t)d_mtc & 3) == 0);
-    const size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
+    const bool ref_point = !(p->match_interval && p->match_interpolated);   // a.rmx is d_ref or null: RowLds<2>
+    const size_t lds = (size_t)W * (nbands == 1 ? (ref_point ? 8 : 4) : 16);
     if (img_ok && lds <= 150 * 1024 && walk_vec(p->disp_n, row_elems, d_cost, nullptr, nullptr) == 4) {
         smk::FusedA fa;
         fa.rn = a.rmn; fa.rx = a.rmx ? a.rmx : a.rmn;
@@ -502,8 +503,13 @@ int smhip_raw_costs(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
         if (xseg < 32) xseg = W < 32 ? W : 32;
         dim3 gr((W + xseg - 1) / xseg, H);
         if (nbands == 1) {
-            if (a.sd) smk::raw_costs_rows_kernel<true, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
-            else      smk::raw_costs_rows_kernel<false, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            if (ref_point && fa.rn == fa.rx) {                    // one band, point reference: RowLds<2>
+                if (a.sd) smk::raw_costs_rows_kernel<true, 2><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+                else      smk::raw_costs_rows_kernel<false, 2><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            } else {
+                if (a.sd) smk::raw_costs_rows_kernel<true, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+                else      smk::raw_costs_rows_kernel<false, 1><<<gr, 256, lds, ctx->stream>>>(fa, d_cost, row_elems, xseg);
+            }
         } else {
             const bool pts = fa.rn == fa.rx && fa.mn == fa.mx;     // point intervals: RowLds<5>
             if (pts) {
@@ -1382,7 +1388,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     // pass A stages whole rows in LDS; rows above 40 KB (4 bands: wider than 2560 pixels) are staged
     // chunk by chunk (smhip_fused_chunk.h); SMHIP_OPT_CHUNK = 1 / 0 forces the choice in tests (and with
     // it the integer kernels)
-    bool chunked = (size_t)W * (p->n_bands == 1 ? 4 : 16) > 40 * 1024;
+    const bool ref_point = !(p->match_interval && p->match_interpolated);   // one band: RowLds<2>, 8 bytes per pixel
+    bool chunked = (size_t)W * (p->n_bands == 1 ? (ref_point ? 8 : 4) : 16) > 40 * 1024;
     const bool chunked_forced = ctx->opt[SMHIP_OPT_CHUNK] >= 0;
     if (chunked_forced) chunked = ctx->opt[SMHIP_OPT_CHUNK] != 0;
     // one band, whole-row kernel: the matching row's Birchfield-Tomasi interval is formed while the row
@@ -1420,7 +1427,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         int tpa = Dp < 256 ? Dp : 256;
         dim3 ga(H, Dp / tpa);
         const int nbands = p->n_bands;
-        size_t lds = (size_t)W * (nbands == 1 ? 4 : 16);
+        size_t lds = (size_t)W * (nbands == 1 ? (ref_point ? 8 : 4) : 16);
         const int adstep = a.dstep < 0 ? -a.dstep : a.dstep;
         const int static_win = (window >= 3 && window <= 17 && (window & 1)) ? window : 0;
         int chunk_steps = static_win ? (480 / static_win) * static_win : 480;
@@ -1429,7 +1436,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (nref > W) nref = W;
         if (nmatch > W) nmatch = W;
         if (chunked)
-            lds = nbands == 1 ? (size_t)(nref + nmatch) * 2     // (four bands: RowLds<4> 8 + 8 bytes, RowLds<6> 4 + 12)
+            lds = nbands == 1 ? (size_t)(nref + nmatch) * (ref_point ? 4 : 2)   // (four bands: RowLds<4> 8 + 8 bytes, RowLds<6> 4 + 12)
                               : (size_t)nref * 8 + (size_t)nmatch * 12;
         if (lds > 150 * 1024)
             return fail(SMHIP_EINVAL, "row staging needs %zu bytes of LDS (width %d, window %d, step %d)", lds, W,
@@ -1458,7 +1465,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         } while (0)
 #define LAUNCH_A(WIN)                                                             \
         do {                                                                      \
-            if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
+            if (nbands == 1 && ref_point && fa.rn == fa.rx) { if (a.sd) LAUNCH_A3(WIN, true, 2); else LAUNCH_A3(WIN, false, 2); } \
+            else if (nbands == 1) { if (a.sd) LAUNCH_A3(WIN, true, 1); else LAUNCH_A3(WIN, false, 1); } \
             else if (fa.rn == fa.rx && fa.mn == fa.mx) { if (a.sd) LAUNCH_A3(WIN, true, 5); else LAUNCH_A3(WIN, false, 5); } \
             else if (fa.rn == fa.rx && !a.sd) LAUNCH_A3(WIN, false, 6); \
             else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \

@@ -95,6 +95,43 @@ template <> struct RowLds<4> {
     }
 };
 
+// NB = 2: ONE band with the reference interval a point (every case but match_interpolated).  A pixel is a 32-bit
+// word: reference r | r << 8 | 255 << 16, matching mn | mx << 8 | (mx - mn) << 16, so that one v_sad_u8 gives
+// |r - mn| + |r - mx| + 255 - (mx - mn) = 2 dist(r, [mn, mx]) + 255: the raw cost is (sad(r, m, -255)) >> 1 -- two
+// instructions instead of unpacking two 16-bit words and a max3 (windows 13 / 17 at 1920x1080x256: pass A 0.428 /
+// 0.411 -> 0.387 ms; raw_costs_rows at 3840x2160x512 stays at 3.25 ms, its stores bound it).
+template <> struct RowLds<2> {
+    uint32_t *r, *m;
+    __device__ static size_t bytes(int W) { return (size_t)W * 8; }
+    __device__ static uint32_t ref_word(int v) { return (uint32_t)v * 0x101u | 0xFF0000u; }
+    __device__ static uint32_t match_word(int lo, int hi) { return (uint32_t)lo | (uint32_t)hi << 8 | (uint32_t)(hi - lo) << 16; }
+    __device__ void init(void *base, int W) { r = (uint32_t *)base; m = r + W; }
+    __device__ void stage(const FusedA &a, size_t ro, int i) const
+    {
+        r[i] = ref_word(a.rn[ro + i]);
+        if (a.bt_inline) {      // BirchfieldTomasiMinMax (StcRawCosts.cpp:107-128), as RowLds<1>
+            const uint8_t *row = a.mn + ro;
+            const int cur = row[i], prv = row[i > 0 ? i - 1 : i], nxt = row[i < a.W - 1 ? i + 1 : i];
+            const int hl = (i > 0) ? (prv + cur + 1) / 2 : cur;
+            const int hr = (cur + nxt + 1) / 2;
+            m[i] = match_word(min(hl, min(cur, hr)), max(hl, max(cur, hr)));
+        } else {
+            m[i] = match_word(a.mn[ro + i], a.mx[ro + i]);
+        }
+    }
+    __device__ void init2(void *base, int nref, int) { r = (uint32_t *)base; m = r + nref; }
+    __device__ void stage_r(const FusedA &a, size_t ro, int src, int slot) const { r[slot] = ref_word(a.rn[ro + src]); }
+    __device__ void stage_m(const FusedA &a, size_t ro, int src, int slot) const
+    {
+        m[slot] = match_word(a.mn[ro + src], a.mx[ro + src]);
+    }
+    template <bool SD> __device__ __forceinline__ int gap(int xr, int xm) const
+    {
+        const int e = (int)(__builtin_amdgcn_sad_u8(r[xr], m[xm], (uint32_t)-255) >> 1);
+        return SD ? e * e : e;
+    }
+};
+
 // NB = 5: four bands with POINT intervals on both sides (no Birchfield-Tomasi sampling): half the staged words,
 // and the SAD of a pixel pair is one v_sad_u8 instead of four interval distances (1920x1080x256, b = 4: pass A
 // 0.48 -> 0.43 ms; a run-time switch inside RowLds<4> cost the interval form 8 %, hence a type of its own)
