@@ -50,6 +50,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the short config 4 / config 5 measurements reported under 'extra'")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0,
+                    help="N = 1: after the timed steps, run the same step for this long and report it under "
+                         "extra.sustained (0: skip)")
     ap.add_argument("--cpu-rows", type=int, default=0,
                     help="rows of the workload the CPU baseline is timed on (default: all)")
     ap.add_argument("--backend", default="nccl",
@@ -88,7 +91,11 @@ def main():
     multi = world > 1 or args.one_rank_rehearsal
     if args.one_rank_rehearsal:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+        if "MASTER_PORT" not in os.environ:          # a port nobody listens on (two sessions may share a box)
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(local_rank)
@@ -213,6 +220,28 @@ def main():
     compute_ms = (sum(e0.elapsed_time(e1) for e0, e1 in produce_events) / len(produce_events) if produce_events
                   else (ms_a + ms_b) / max(1, n_prof))
 
+    sustained = None
+    if not multi and not args.check_oracle and args.sustained_seconds > 0:
+        # the same step for >= 2 s, after the timed region (the headline is the K steps above): what the part holds
+        # once clocks and temperature have settled, with the spread of the per-launch times
+        n_s = max(args.steps, int(args.sustained_seconds / (dt / args.steps)) + 1)
+        if profiling:
+            ctx.profile_begin(n_s)
+        t0s = time.perf_counter()
+        for _ in range(n_s):
+            step()
+        fence()
+        dts = time.perf_counter() - t0s
+        sustained = {"seconds": round(dts, 3), "steps": n_s, "ms_per_step": round(dts / n_s * 1e3, 4),
+                     "value": round(W * H * D * n_s / dts / 1e9, 2), "unit": "G pixel*disparity/s"}
+        if profiling:
+            pa, pb = ctx.profile_get(0, n_s)
+            ctx.profile_end()
+            for name, xs in (("pass_a_ms", pa), ("pass_b_ms", pb)):
+                xs = sorted(xs)
+                sustained[name] = {"min": round(xs[0], 4), "median": round(xs[len(xs) // 2], 4),
+                                   "p99": round(xs[int(len(xs) * 0.99)], 4), "max": round(xs[-1], 4)}
+
     t = torch.tensor([dt, compute_ms], dtype=torch.float64, device="cpu" if args.backend != "nccl" and multi else dev)
     per_rank_compute = [compute_ms]
     if multi:
@@ -256,8 +285,7 @@ def main():
             if per:
                 r["ms_per_launch"] = stats(per)
             return r
-        one_band_unit = b == 1                       # the float-lane pass A covers it (window 5..11)
-        name_a = "fused_rawbox_h_f_kernel" if one_band_unit and win in (3, 5, 7, 9, 11) else "fused_rawbox_h_lds_kernel"
+        name_a = ctx.last_pass_a_kernel()            # the library names the pass A kernel its dispatcher took
         ka = roof(name_a, bytes_a, ta, per_call[0])
         kb = roof("fused_boxv_wta_vpl_kernel", bytes_b, tb, per_call[1])
         dominant = ka if ta >= tb else kb
@@ -300,6 +328,8 @@ def main():
             out["frames_checked_vs_oracle"] = frames_checked[0]
         if extra is not None:
             out["extra"] = extra
+        if sustained is not None:
+            out.setdefault("extra", {})["sustained"] = sustained
         if not multi and not args.no_cpu_baseline:
             got = (disp.cpu().numpy(), best.cpu().numpy())         # the frame the timed loop left behind
             out["cpu_baseline"], ok = cpu_baseline(np, left, right, args, Dg, win, got=got)

@@ -84,6 +84,9 @@ enum smhip_option {
     SMHIP_OPT_B_WAVES,        /* pass B waves resident per CU, 6..16 (even; bounded through the LDS a workgroup asks for); 0 no bound */
     SMHIP_OPT_STAGE_LDS_KB,   /* LDS floor of the stage kernels, KiB, 0..80 (bounds the workgroups per CU) */
     SMHIP_OPT_B_AHEAD,        /* pass B of slabs up to 128 levels: 1 = one block of rows in flight, 2 = two; default two, four on up to 2048 columns */
+    SMHIP_OPT_MULTI_TXT,      /* pixels per tile of the multi-iteration binomial pass, halo included: 64 or 128 (default: 128 from 1 GiB on) */
+    SMHIP_OPT_TAP_SLOW,       /* 1: the binomial passes always take the plain ten-operation tap sum (tests) */
+    SMHIP_OPT_MULTI_PX,       /* multi-iteration binomial pass with pixels on lanes (width % 4 == 0): 16 / 32 levels per workgroup; 0 / default: off */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);
@@ -318,6 +321,10 @@ int smhip_profile_begin(smhip_ctx *ctx, int max_calls);
 int smhip_profile_end(smhip_ctx *ctx, int *n_calls, float *ms_pass_a, float *ms_pass_b);
 /* per-call times of the profiled calls [first, first + count) (waits for the stream); before _end */
 int smhip_profile_get(smhip_ctx *ctx, int first, int count, float *ms_pass_a, float *ms_pass_b);
+/* Name of the pass A kernel the context's most recent fused call launched ("" before the first call): the
+ * dispatcher picks among four kernels by shape and options, and a report should name the one that ran
+ * (the printf lines of CudaRawCosts.cu:381-420 name their one kernel). */
+const char *smhip_last_pass_a_kernel(const smhip_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -26,6 +26,7 @@ SYMBOLS = [
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
     "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run", "smhip_pad_wta_keys",
+    "smhip_last_pass_a_kernel",
 ]
 
 
@@ -146,9 +147,11 @@ def load():
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     L.smhip_profile_get.argtypes = [vp, ci, ci, C.POINTER(cf), C.POINTER(cf)]
+    L.smhip_last_pass_a_kernel.argtypes = [vp]
+    L.smhip_last_pass_a_kernel.restype = C.c_char_p
     for name in SYMBOLS:
         f = getattr(L, name)
-        if name not in ("smhip_last_error", "smhip_workspace_bytes", "smhip_match_outside"):
+        if name not in ("smhip_last_error", "smhip_workspace_bytes", "smhip_match_outside", "smhip_last_pass_a_kernel"):
             f.restype = ci
     _lib = L
     return L
@@ -181,7 +184,7 @@ def _ptr(x):
 
 
 # enum smhip_option (include/smhip.h)
-OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13}
+OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13, "multi_txt": 14, "tap_slow": 15, "multi_px": 16}
 
 
 class Context:
@@ -407,6 +410,10 @@ class Context:
         a, b = (C.c_float * count)(), (C.c_float * count)()
         self._chk(self.L.smhip_profile_get(self.h, first, count, a, b))
         return list(a), list(b)
+
+    def last_pass_a_kernel(self):
+        """Name of the pass A kernel the most recent fused call launched."""
+        return self.L.smhip_last_pass_a_kernel(self.h).decode()
 
     def profile_end(self):
         """Returns (n_calls, total ms of pass A, total ms of pass B)."""

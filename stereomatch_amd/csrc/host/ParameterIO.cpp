@@ -39,8 +39,10 @@ void CParameterIO::Param::Parse(const std::string &value) const
     }
     case Kind::Hex:                                    // written as 0x%08x, read back the same way
         if (value.size() > 2 && s[0] == '0' && s[1] == 'x') {
-            unsigned long v = strtoul(value.substr(2, 8).c_str(), &end, 16);
-            *static_cast<int *>(loc) = (int)(unsigned)v;
+            const std::string digits = value.substr(2, 8);
+            unsigned long v = strtoul(digits.c_str(), &end, 16);
+            if (end != digits.c_str())                 // no hex digit after "0x": the variable keeps its value, as with scanf
+                *static_cast<int *>(loc) = (int)(unsigned)v;
         }
         break;
     }

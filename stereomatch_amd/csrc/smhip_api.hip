@@ -11,11 +11,13 @@
 #include "smhip_stage.h"
 #include "smhip_refine.h"
 #include "smhip_multi.h"
+#include "smhip_multi_px.h"
 #include "smhip_opt.h"
 #include "smhip_bayes.h"
 #include "smhip_dp.h"
 
 #include <math.h>
+#include <mutex>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -52,7 +54,8 @@ enum { WS_TMP = 0, WS_BT = 1, WS_KEYS = 2, WS_COUNT = 3 };
 // an address: smhip_init asks for the device's address once (hipGetSymbolAddress) and keeps it.
 static __device__ __align__(256) unsigned char smhip_static_scratch[SMHIP_NOALLOC_SCRATCH_BYTES];
 enum { SMHIP_MAX_DEVICES = 64 };
-static unsigned char *g_scratch_ptr[SMHIP_MAX_DEVICES];   // per device, filled by smhip_init
+static unsigned char *g_scratch_ptr[SMHIP_MAX_DEVICES];   // per device, filled by smhip_init under g_scratch_mu
+static std::mutex g_scratch_mu;
 
 struct smhip_ctx {
     int device;
@@ -65,6 +68,7 @@ struct smhip_ctx {
     int bayes_n, bayes_band;             // levels they were computed for (0: none), half band width
     float bayes_sigma, bayes_eps;
     int opt[SMHIP_OPT_COUNT];            // smhip_set_option; -1 = the library's own policy
+    const char *last_pass_a;             // kernel of the most recent fused call's pass A (smhip_last_pass_a_kernel)
     // no-allocation mode (inside smhip_fused_box_wta_noalloc): the workspace slots are carved out of this
     // device's static scratch array instead of hipMalloc'ed
     unsigned char *scratch;              // this device's address of smhip_static_scratch
@@ -284,6 +288,7 @@ int smhip_init(int device, smhip_ctx **out)
     ctx->device = device;
     ctx->stream = nullptr;
     if (device < SMHIP_MAX_DEVICES) {    // this device's copy of the static scratch (device is current)
+        std::lock_guard<std::mutex> lock(g_scratch_mu);      // contexts may be created from several host threads
         if (!g_scratch_ptr[device]) {
             void *sp = nullptr;
             hipError_t e = hipGetSymbolAddress(&sp, HIP_SYMBOL(smhip_static_scratch));
@@ -303,8 +308,8 @@ int smhip_init(int device, smhip_ctx **out)
 
 int smhip_set_option(smhip_ctx *ctx, int option, int value)
 {
-    if (!ctx)
-        return fail(SMHIP_EINVAL, "null context");
+    int rc = check_ctx(ctx);            // also makes the context's device current for the synchronize below
+    if (rc) return rc;
     if (option < 0 || option >= SMHIP_OPT_COUNT)
         return fail(SMHIP_EINVAL, "unknown option %d", option);
     if (option == SMHIP_OPT_TYSHIFT && value > 8)
@@ -315,6 +320,8 @@ int smhip_set_option(smhip_ctx *ctx, int option, int value)
         return fail(SMHIP_EINVAL, "pass A LDS floor %d KiB above 80 (two workgroups per CU)", value);
     if (option == SMHIP_OPT_B_WAVES && value > 0 && (value < 6 || value > 16))
         return fail(SMHIP_EINVAL, "pass B waves per CU %d outside 6..16 (0: no bound)", value);
+    if (option == SMHIP_OPT_MULTI_TXT && value >= 0 && value != 64 && value != 128)
+        return fail(SMHIP_EINVAL, "binomial tile width %d: 64 or 128", value);
     // the slab layout and the kernels of calls already queued must not change under them
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->opt[option] = value < 0 ? -1 : value;
@@ -343,14 +350,19 @@ int smhip_shutdown(smhip_ctx *ctx)
 
 int smhip_set_stream(smhip_ctx *ctx, void *hip_stream)
 {
-    if (!ctx)
-        return fail(SMHIP_EINVAL, "null context");
+    int rc = check_ctx(ctx);            // the context's device is current from here on (null stream = its null stream)
+    if (rc) return rc;
     // The workspaces (slab, interval images, partial keys) belong to the context, not to a stream: work
     // queued on the old stream may still be reading them, so the old stream is drained first.
     if ((hipStream_t)hip_stream != ctx->stream)
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->stream = (hipStream_t)hip_stream;
     return SMHIP_OK;
+}
+
+const char *smhip_last_pass_a_kernel(const smhip_ctx *ctx)
+{
+    return ctx && ctx->last_pass_a ? ctx->last_pass_a : "";
 }
 
 int smhip_sync(smhip_ctx *ctx)
@@ -879,9 +891,9 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
         return fail(SMHIP_EINVAL, "negative iteration count");
     float *cur = d_a, *oth = d_b;
     *result_in_b = 0;
-    const int tseg = tile_seglen(ctx, w, h, nb);
-    const unsigned gy = (nb + 31) / 32, gz = (h + tseg - 1) / tseg;
-    if (walk_vec(nb, row_elems, d_a, d_b, nullptr) != 4 || gy > 65535 || gz > 65535) {
+    const int tseg0 = tile_seglen(ctx, w, h, nb);
+    const unsigned gy = (nb + 31) / 32;
+    if (walk_vec(nb, row_elems, d_a, d_b, nullptr) != 4 || gy > 65535 || (h + tseg0 - 1) / tseg0 > 65535) {
         for (int i = 0; i < n_iter; i++) {
             rc = smhip_convolve_14641_to(ctx, cur, oth, w, h, nb, row_elems);
             if (rc) return rc;
@@ -898,12 +910,60 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
             rc = smhip_convolve_14641_to(ctx, cur, oth, w, h, nb, row_elems);
             if (rc) return rc;
         } else {
-            dim3 grid((w + (smk::MULTI_TXT - 4 * K) - 1) / (smk::MULTI_TXT - 4 * K), gy, gz);
-            switch (K) {
-            case 2: smk::binomial_multi_kernel<2><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
-            case 3: smk::binomial_multi_kernel<3><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
-            default: smk::binomial_multi_kernel<4><<<grid, smk::MULTI_TXT * 8, stage_lds(ctx), ctx->stream>>>(cur, oth, w, nb, h, row_elems, tseg); break;
+            // Tile shape (3840x2160x512, K = 4, scripts/bench_binom.py -> profiles/r03_binom_variants.log): 64 pixels x
+            // 128 rows 10.7 ms, 128 pixels (1024 threads, one workgroup per CU) 9.6, with 256-row segments 9.2 --
+            // the halo's share of the arithmetic falls from 1.50 to 1.21.  Small volumes keep the 64-pixel tile
+            // (more, smaller workgroups).  The pixels-on-lanes kernel (smhip_multi_px.h) is 9.5 ms here: an option.
+            const size_t vol = row_elems * (size_t)h * sizeof(float);
+            const bool big = vol >= ((size_t)1 << 30) && w >= 1024;
+            const int txt = ctx->opt[SMHIP_OPT_MULTI_TXT] > 0 ? ctx->opt[SMHIP_OPT_MULTI_TXT] : (big ? 128 : 64);
+            const int slow = ctx->opt[SMHIP_OPT_TAP_SLOW] == 1;                 // tests: the ten-operation tap sum
+            const int pxo = ctx->opt[SMHIP_OPT_MULTI_PX];
+            int tseg = tseg0;
+            if (big && ctx->opt[SMHIP_OPT_TSEG] < 0 && h >= 512)
+                tseg = 256;
+            const unsigned gz = (h + tseg - 1) / tseg;
+            if (w % 4 == 0 && pxo > 0) {        // pixels on lanes (smhip_multi_px.h)
+                const int lv = pxo == 16 ? 16 : 32;
+                dim3 grid((w + smk::px_txi(K) - 1) / smk::px_txi(K), (nb + lv - 1) / lv, gz);
+#define LAUNCH_PX(KK, LL) smk::binomial_px_kernel<KK, LL><<<grid, LL * 32, stage_lds(ctx), ctx->stream>>>( \
+                    cur, oth, w, nb, h, row_elems, tseg, slow)
+                if (lv == 32) {
+                    switch (K) {
+                    case 2: LAUNCH_PX(2, 32); break;
+                    case 3: LAUNCH_PX(3, 32); break;
+                    default: LAUNCH_PX(4, 32); break;
+                    }
+                } else {
+                    switch (K) {
+                    case 2: LAUNCH_PX(2, 16); break;
+                    case 3: LAUNCH_PX(3, 16); break;
+                    default: LAUNCH_PX(4, 16); break;
+                    }
+                }
+#undef LAUNCH_PX
+                left -= K;
+                float *t = cur; cur = oth; oth = t;
+                *result_in_b ^= 1;
+                continue;
             }
+            dim3 grid((w + (txt - 4 * K) - 1) / (txt - 4 * K), gy, gz);
+#define LAUNCH_BM(KK, TT) smk::binomial_multi_kernel<KK, TT><<<grid, TT * 8, stage_lds(ctx), ctx->stream>>>( \
+                cur, oth, w, nb, h, row_elems, tseg, slow)
+            if (txt == 128) {
+                switch (K) {
+                case 2: LAUNCH_BM(2, 128); break;
+                case 3: LAUNCH_BM(3, 128); break;
+                default: LAUNCH_BM(4, 128); break;
+                }
+            } else {
+                switch (K) {
+                case 2: LAUNCH_BM(2, 64); break;
+                case 3: LAUNCH_BM(3, 64); break;
+                default: LAUNCH_BM(4, 64); break;
+                }
+            }
+#undef LAUNCH_BM
         }
         left -= K;
         float *t = cur; cur = oth; oth = t;
@@ -1398,9 +1458,9 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     const bool bt_inline = tuned_a && !chunked && p->n_bands == 1 && p->match_interval &&
                            !p->match_interpolated && ctx->opt[SMHIP_OPT_BT_PREPASS] != 1;
 
-    smk::RawArgs a;
-    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
-    if (rc) return rc;
+    // every workspace request comes before the first launch (prepare_raw asks for the interval images and then
+    // runs the pre-pass): a call that cannot get its memory -- the no-allocation entry point on a problem beyond
+    // its static scratch -- is refused with nothing queued
     void *T = nullptr;
     rc = ws_get(ctx, WS_TMP, t_elems * sizeof(float), &T);
     if (rc) return rc;
@@ -1411,12 +1471,16 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (rc) return rc;
         kout = (long long *)part;
     }
+    smk::RawArgs a;
+    rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
+    if (rc) return rc;
     float scale = (float)(1.0 / window);
     float outside = smhip_match_outside(p);
 
     bool prof = ctx->ev && ctx->ev_used < ctx->ev_cap;
     hipEvent_t *ev = prof ? ctx->ev + 3 * ctx->ev_used : nullptr;
     if (prof) HIP_TRY(hipEventRecord(ev[0], ctx->stream));
+    bool float_a_ran = false;
     if (tuned_a) {
         smk::FusedA fa;
         fa.rn = a.rmn; fa.rx = a.rmx ? a.rmx : a.rmn;
@@ -1471,6 +1535,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             else if (fa.rn == fa.rx && !a.sd) LAUNCH_A3(WIN, false, 6); \
             else             { if (a.sd) LAUNCH_A3(WIN, true, 4); else LAUNCH_A3(WIN, false, 4); } \
         } while (0)
+        float_a_ran = float_a;
         if (!float_a)
         switch (window) {            // static windows: the leaving cost comes from a register ring
         case 3: LAUNCH_A(3); break;
@@ -1490,6 +1555,8 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         smk::fused_rawbox_h_kernel<<<(unsigned)((chains + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             a, (float *)T, trow, Dp, window, scale);
     }
+    ctx->last_pass_a = !tuned_a ? "fused_rawbox_h_kernel" : float_a_ran ? "fused_rawbox_h_f_kernel"
+                       : chunked ? "fused_rawbox_h_chunk_kernel" : "fused_rawbox_h_lds_kernel";
     if (prof) HIP_TRY(hipEventRecord(ev[1], ctx->stream));
 
     if (wide) {

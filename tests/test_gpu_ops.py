@@ -364,6 +364,44 @@ def test_multi_iteration_passes(gpu_ctx, oracle, h, w, d, pad, n_iter, maxk, req
     util.assert_bit_equal(result(bufs, in_b), want, "binomial x%d" % n_iter)
 
 
+@pytest.mark.parametrize("kind", ["tiny", "subnormal", "negative", "late_tiny", "signed_zero", "plain"])
+@pytest.mark.parametrize("opts", [{}, {"tap_slow": 1}, {"multi_px": 0, "multi_txt": 128}, {"maxk": 3}, {"multi_px": 0},
+                                  {"multi_px": 32}, {"multi_px": 0, "tap_slow": 1}])
+def test_binomial_tap_guard(gpu_ctx, oracle, kind, opts, request):
+    """The multi-iteration binomial pass takes the 2^-4 and 2^-2 taps as exact-product FMAs (same bits as the
+    reference's multiply-then-add, Convolve.cpp:100-107) only while every input of the workgroup is zero or at
+    least 2^-80 and carries no sign bit; otherwise it falls back to the ten-operation sum.  Inputs that would
+    expose a difference -- values whose products are subnormal (a rounded product loses bits an FMA keeps),
+    negative values, -0 -- must therefore still match the oracle bit for bit, wherever in the volume they sit."""
+    for k, v in dict({"maxk": 4}, **opts).items():
+        gpu_ctx.set_option(k, v)
+        request.addfinalizer(lambda k=k: gpu_ctx.set_option(k, -1))
+    h, w, d = 90, 152, 40
+    rng = np.random.RandomState(7)
+    c = (rng.rand(h, w, d) * 1000.0).astype(np.float32)
+    c[rng.rand(h, w, d) < 0.3] = 0.0
+    if kind == "tiny":              # products around 2^-100 .. 2^-126 after a few iterations
+        c *= np.float32(1e-30)
+    elif kind == "subnormal":       # the boundary itself: inputs in the subnormal range and just above
+        c[:, :w // 2] *= np.float32(1e-36)
+        c[:, w // 2:] = (rng.rand(h, w - w // 2, d) * 3e-38).astype(np.float32)
+    elif kind == "negative":
+        c[40:50, 60:70] -= np.float32(500.0)
+    elif kind == "late_tiny":       # one tiny value deep inside a segment, in the halo column of a tile
+        c[77, 47, 13] = np.float32(3.1e-33)
+        c[78, 48, 14] = np.float32(1.7e-39)
+    elif kind == "signed_zero":
+        c[rng.rand(h, w, d) < 0.1] = np.float32(-0.0)
+    for n_iter in (4, 8):
+        want = c
+        for _ in range(n_iter):
+            want = oracle.convolve_14641(want)
+        bufs = (up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4))
+        in_b = gpu_ctx.convolve_14641_run(bufs[0], bufs[1], w, h, d, w * d, n_iter)
+        util.assert_bit_equal(gpu_ctx.download(bufs[1] if in_b else bufs[0], (h, w, d), np.float32), want,
+                              "binomial x%d on %s inputs" % (n_iter, kind))
+
+
 def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, request):
     """Large volumes use 128-row segments in the LDS-tiled kernels; force that length on a small
     volume (the `tseg` option) so the segment logic of the production configuration is covered."""
