@@ -430,13 +430,23 @@ def extra_configs(np, capi, synth, ctx):
             ctx.raw_costs(d_ref, d_mtc, W, ps, a, W * n)
             in_b = ctx.convolve_14641_run(a, b, W, H, n, W * n, 4)
             ctx.pad_wta_keys(b if in_b else a, W * n, p, d0, n, keys)
-        dt = timed(slab_step, 3)
-        res["config4_slab_pipeline"] = {
-            "workload": "3840x2160, levels 256..319 of D=512 (one GPU's share of 8): raw costs + 4 binomial "
-                        "iterations + PadCosts + WTA -> keys",
-            "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(W * H * n / dt / 1e9, 1)}
+        dt_staged = timed(slab_step, 3)
         a.free()
         b.free()
+        # the same through smhip_fused_iter_wta_keys: one kernel, no DSI (smhip_iter_px.h)
+        dt = timed(lambda: ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, 2, 4, d0, n, keys), 5)
+        res["config4_slab_pipeline"] = {
+            "workload": "3840x2160, levels 256..319 of D=512 (one GPU's share of 8): raw costs + 4 binomial "
+                        "iterations + PadCosts + WTA -> keys, fused (smhip_fused_iter_wta_keys: no DSI traffic, "
+                        "VALU-bound)",
+            "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(W * H * n / dt / 1e9, 1),
+            "ms_stage_calls": round(dt_staged * 1e3, 3)}
+        for iters in (4, 8):
+            dt = timed(lambda: [ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, 2, iters, s0, 256, keys) for s0 in (0, 256)], 2)
+            res["config4_fused_binomial_x%d" % iters] = {
+                "workload": "3840x2160, D=512 in two calls of 256 levels: raw costs + %d binomial iterations + "
+                            "PadCosts + WTA -> keys, fused" % iters,
+                "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(N / dt / 1e9, 1)}
         keys.free()
     except Exception as e:      # noqa: BLE001 - reported, the headline line must still print
         res["config4_error"] = repr(e)

@@ -87,6 +87,9 @@ enum smhip_option {
     SMHIP_OPT_MULTI_TXT,      /* pixels per tile of the multi-iteration binomial pass, halo included: 64 or 128 (default: 128 from 1 GiB on) */
     SMHIP_OPT_TAP_SLOW,       /* 1: the binomial passes always take the plain ten-operation tap sum (tests) */
     SMHIP_OPT_MULTI_PX,       /* multi-iteration binomial pass with pixels on lanes (width % 4 == 0): 16 / 32 levels per workgroup; 0 / default: off */
+    SMHIP_OPT_ITER_FUSED,     /* smhip_fused_iter_wta_keys: 0 = always the stage calls on a private DSI (tests) */
+    SMHIP_OPT_ITER_GROUPS,    /* smhip_fused_iter_wta_keys: level groups (workgroups along the levels) of the keys kernels, 1..16 */
+    SMHIP_OPT_A_NW,           /* 1: float-lane pass A in one-wave workgroups (128 levels each) also on 256-level chunks */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);
@@ -299,6 +302,21 @@ int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int heig
 int smhip_fused_box_wta(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                         size_t img_pitch, const smhip_match_params *p, int window,
                         int32_t *d_disp, float *d_best);
+
+/* Fused path of the ITERATED aggregators: raw costs (StcRawCosts.cpp:229-435) -> n_iter iterations of aggr_fn
+ * (2 = binomial 14641, StcAggregate.cpp:280-289; 3 = diffusion, 4 = membrane, :298-318, StcDiffusion.cpp:28-137)
+ * -> PadCosts (:365) -> OptWTA (StcOptimize.cpp:26-56) on levels [d_first, d_first + d_count) -> one 64-bit key
+ * per pixel, as smhip_fused_box_wta_keys.  Binomial with n_iter <= 4 (unit disparity step denominators, width % 4
+ * == 0, one band with a point reference interval or four bands, |disparity step| <= 16) runs as ONE kernel that
+ * moves no DSI at all: raw costs are formed in the tile, the iterations run in registers, the winners collect in
+ * LDS.  More binomial iterations bracket the multi-iteration passes of smhip_convolve_14641_run between a
+ * "raw costs + first iterations -> DSI" and a "last iterations + PadCosts + WTA -> keys" kernel.  Every other case
+ * (diffusion / membrane, other shapes) runs the stage calls on a private DSI and gives the same keys.
+ * lambda, beta: diff_lambda / diff_beta (membrane only; diffusion forces beta = 0, StcAggregate.cpp:305).
+ * n_iter = 0 is allowed (raw costs -> PadCosts -> WTA). */
+int smhip_fused_iter_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                              const smhip_match_params *p, int aggr_fn, int n_iter, float lambda, float beta,
+                              int d_first, int d_count, int64_t *d_keys);
 
 /* The same call for callers that cannot allocate device memory (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc): no counterpart in the reference.  The slab of

@@ -26,7 +26,7 @@ SYMBOLS = [
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
     "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run", "smhip_pad_wta_keys",
-    "smhip_last_pass_a_kernel",
+    "smhip_last_pass_a_kernel", "smhip_fused_iter_wta_keys",
 ]
 
 
@@ -147,6 +147,7 @@ def load():
     L.smhip_profile_begin.argtypes = [vp, ci]
     L.smhip_profile_end.argtypes = [vp, C.POINTER(ci), C.POINTER(cf), C.POINTER(cf)]
     L.smhip_profile_get.argtypes = [vp, ci, ci, C.POINTER(cf), C.POINTER(cf)]
+    L.smhip_fused_iter_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, cf, cf, ci, ci, vp]
     L.smhip_last_pass_a_kernel.argtypes = [vp]
     L.smhip_last_pass_a_kernel.restype = C.c_char_p
     for name in SYMBOLS:
@@ -184,7 +185,7 @@ def _ptr(x):
 
 
 # enum smhip_option (include/smhip.h)
-OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13, "multi_txt": 14, "tap_slow": 15, "multi_px": 16}
+OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13, "multi_txt": 14, "tap_slow": 15, "multi_px": 16, "iter_fused": 17, "iter_groups": 18, "a_nw": 19}
 
 
 class Context:
@@ -348,6 +349,12 @@ class Context:
     def min_pad_wta_keys(self, d_cost, row_elems, p, min_window, d_first, d_count, d_keys):
         self._chk(self.L.smhip_min_pad_wta_keys(self.h, _ptr(d_cost), row_elems, C.byref(p), min_window,
                                                 d_first, d_count, _ptr(d_keys)))
+
+    def fused_iter_wta_keys(self, d_ref, d_mtc, img_pitch, p, aggr_fn, n_iter, d_first, d_count, d_keys,
+                            diff_lambda=0.15, diff_beta=0.5):
+        """Raw costs -> n_iter iterations of aggr_fn (2 binomial, 3 diffusion, 4 membrane) -> PadCosts -> WTA keys."""
+        self._chk(self.L.smhip_fused_iter_wta_keys(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch, C.byref(p), aggr_fn,
+                                                   n_iter, diff_lambda, diff_beta, d_first, d_count, _ptr(d_keys)))
 
     def pad_wta_keys(self, d_cost, row_elems, p, d_first, d_count, d_keys):
         self._chk(self.L.smhip_pad_wta_keys(self.h, _ptr(d_cost), row_elems, C.byref(p), d_first, d_count,

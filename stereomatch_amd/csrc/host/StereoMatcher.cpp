@@ -50,6 +50,15 @@ bool CStereoMatcher::Fusable() const
            m_disp_den == 1 && verbose < eVerboseDumpFiles;
 }
 
+bool CStereoMatcher::IterFusable() const
+{
+    // binomial iterations + WTA and nothing downstream needs the DSI: smhip_fused_iter_wta_keys (aggr_iter <= 4 as
+    // one kernel that moves no DSI, more between its raw-cost and its WTA end)
+    return allow_fused && aggr_fn == eBinomial && aggr_iter >= 1 && aggr_minfilter <= 1 && opt_fn == eWTA &&
+           !refine_subpix && !aggr_subpixel && !aggr_collapse && !eval_match_quality &&
+           m_disp_den == 1 && m_disp_n <= 65535 && verbose < eVerboseDumpFiles;
+}
+
 bool CStereoMatcher::BoxDsiFusable() const
 {
     // RawCosts + one AggrBox in two passes over a private slab (12 instead of 20 bytes per voxel)
@@ -178,6 +187,15 @@ void CStereoMatcher::ComputeCorrespondence()
         Check(smhip_fused_box_wta(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
                                   m_reference.RowBytes(), &m_mp, aggr_window_size,
                                   (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
+    } else if (IterFusable()) {
+        m_used_fused = true;
+        if (verbose >= eVerboseProgress)
+            fprintf(stderr, "- fused device pass: costs, binomial filter iterated %d times, pad, WTA\n", aggr_iter);
+        Check(smhip_fused_iter_wta_keys(m_ctx, (const uint8_t *)m_dev[B_REF], (const uint8_t *)m_dev[B_MTC],
+                                        m_reference.RowBytes(), &m_mp, aggr_fn, aggr_iter, diff_lambda, diff_beta, 0,
+                                        m_disp_n, (int64_t *)DeviceBuffer(B_KEYS, n_pix * sizeof(int64_t))));
+        Check(smhip_keys_decode(m_ctx, (const int64_t *)m_dev[B_KEYS], m_mp.width, m_mp.height,
+                                (int32_t *)m_dev[B_DISP], (float *)m_dev[B_BEST]));
     } else {
         RawCosts();
         Aggregate();

@@ -62,6 +62,7 @@ protected:
     bool m_used_fused = false;
     bool m_raw_deferred = false;        // RawCosts + AggrBox run as one smhip_fused_box_dsi call
     bool m_keys_done = false;           // AggrMin + PadCosts + OptWTA already ran as smhip_min_pad_wta_keys
+    bool IterFusable() const;
     bool BoxDsiFusable() const;
     bool MinWtaFusable() const;
     bool m_have_mind = false;           // m_sub_pixel_min holds offsets (StcAggregate.cpp:77,228)

@@ -12,6 +12,8 @@
 #include "smhip_refine.h"
 #include "smhip_multi.h"
 #include "smhip_multi_px.h"
+#include "smhip_iter_px.h"
+#include "smhip_iter_px_launch.h"
 #include "smhip_opt.h"
 #include "smhip_bayes.h"
 #include "smhip_dp.h"
@@ -1511,12 +1513,13 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (!chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0) {
             const int max_cost = nbands * (a.sd ? 255 * 255 : 255), pol = ctx->opt[SMHIP_OPT_STORE_POLICY];
             const long a_lds_min = ctx->opt[SMHIP_OPT_A_LDS_KB] < 0 ? -1 : (long)ctx->opt[SMHIP_OPT_A_LDS_KB] * 1024;
+            const int a_one_wave = ctx->opt[SMHIP_OPT_A_NW] == 1;
             if (paired)
                 paired = smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, 4,
-                                                      a.sd != 0, max_cost, ctx->stream, pol, true, a_lds_min);
+                                                      a.sd != 0, max_cost, ctx->stream, pol, true, a_lds_min, a_one_wave);
             float_a = paired || smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale,
                                                              keep_all, CH / 64, a.sd != 0, max_cost, ctx->stream,
-                                                             pol, false, a_lds_min);
+                                                             pol, false, a_lds_min, a_one_wave);
         } else {
             paired = false;
         }
@@ -1803,6 +1806,178 @@ int smhip_pad_wta_keys(smhip_ctx *ctx, float *d_cost, size_t row_elems, const sm
     smk::keys_encode_t_kernel<<<grid, 256, stage_lds(ctx), ctx->stream>>>(disp, best, w, h, d_first, (long long *)d_keys);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
+}
+
+// Rows per workgroup of the keys kernels of smhip_iter_px.h: IPX_SEG at most (the keys of a segment live in LDS),
+// shorter where the frame would give too few workgroups.
+static int iter_keys_seglen(const smhip_ctx *ctx, int w, int h, int K)
+{
+    const int txi = smk::iter_px_tile_pixels(K);
+    int seg = smk::IPX_SEG;
+    while (seg > 16 && (long)((w + txi - 1) / txi) * ((h + seg - 1) / seg) < 512)
+        seg >>= 1;
+    if (ctx->opt[SMHIP_OPT_TSEG] >= 8 && ctx->opt[SMHIP_OPT_TSEG] <= smk::IPX_SEG)
+        seg = ctx->opt[SMHIP_OPT_TSEG];
+    return seg;
+}
+
+// Launch of a keys-sink kernel of smhip_iter_px.h: the level tiles are dealt to G workgroup groups (blockIdx.y);
+// with G > 1 every group writes a key image of its own and keys_min_kernel merges them.
+static int launch_iter_keys(smhip_ctx *ctx, int K, int src, int nbk, bool sd, smk::IterPxArgs &g, int64_t *d_keys)
+{
+    const int w = g.W, h = g.H, lv = smk::iter_px_levels(src, smk::IPX_KEYS), txi = smk::iter_px_tile_pixels(K);
+    const int n_tiles = (g.D + lv - 1) / lv;
+    const int seg = iter_keys_seglen(ctx, w, h, K);
+    const unsigned gx = (w + txi - 1) / txi, gz = (h + seg - 1) / seg;
+    // enough workgroups for a few full rounds of the chip (two 512-thread or one 1024-thread workgroup per CU)
+    int G = 1;
+    const long per_round = lv == 16 ? 512 : 256;
+    while (G < n_tiles && G < 16 && (long)gx * gz * G < 4 * per_round)
+        G++;
+    if (ctx->opt[SMHIP_OPT_ITER_GROUPS] >= 1)
+        G = ctx->opt[SMHIP_OPT_ITER_GROUPS] < n_tiles ? ctx->opt[SMHIP_OPT_ITER_GROUPS] : n_tiles;
+    if (G > 16) G = 16;
+    g.tiles_per_group = (n_tiles + G - 1) / G;
+    G = (n_tiles + g.tiles_per_group - 1) / g.tiles_per_group;     // no empty group
+    g.seglen = seg;
+    const size_t n_pix = (size_t)w * h;
+    g.part_stride = n_pix;
+    g.pw.keys = (long long *)d_keys;
+    if (G > 1) {
+        void *part = nullptr;
+        int rc = ws_get(ctx, WS_KEYS, n_pix * G * sizeof(long long), &part);
+        if (rc) return rc;
+        g.pw.keys = (long long *)part;
+    }
+    if (gz > 65535)
+        return fail(SMHIP_EINVAL, "iterated fused path: more than %d rows", 65535 * seg);
+    if (!smk::launch_iter_px(K, src, smk::IPX_KEYS, nbk, sd, g, gx, (unsigned)G, gz, ctx->stream))
+        return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K);
+    if (G > 1)
+        smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
+            g.pw.keys, G, n_pix, (long long *)d_keys);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+int smhip_fused_iter_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
+                              const smhip_match_params *p, int aggr_fn, int n_iter, float lambda, float beta,
+                              int d_first, int d_count, int64_t *d_keys)
+{
+    int rc = check_ctx(ctx);
+    if (rc) return rc;
+    rc = check_params(p, d_ref, d_mtc, img_pitch);
+    if (rc) return rc;
+    if (!d_keys)
+        return fail(SMHIP_EINVAL, "null key buffer");
+    if (d_first < 0 || d_count < 1 || d_first + d_count > p->disp_n)
+        return fail(SMHIP_EINVAL, "disparity slab [%d,%d) outside [0,%d)", d_first, d_first + d_count, p->disp_n);
+    if (aggr_fn < 2 || aggr_fn > 4)
+        return fail(SMHIP_EINVAL, "iterated fused path: aggr_fn %d is not binomial (2), diffusion (3) or membrane (4)", aggr_fn);
+    if (n_iter < 0)
+        return fail(SMHIP_EINVAL, "negative iteration count");
+    if (p->disp_den != 1)
+        return fail(SMHIP_EINVAL, "iterated fused path: disp_step < 1 not supported, use the stage calls");
+    if (d_count > 65535)
+        return fail(SMHIP_EINVAL, "iterated fused path: more than 65535 levels in one call");
+    const int W = p->width, H = p->height, nb = p->n_bands;
+    const int dstep = -p->frame_diff_sign * p->disp_num;
+    const bool ref_point = !(p->match_interval && p->match_interpolated);
+    const bool img4 = nb == 4 && img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 && ((uintptr_t)d_mtc & 3) == 0;
+    const int nbk = (nb == 1 && ref_point) ? 2 : (img4 ? 4 : 0);
+    const bool px_ok = aggr_fn == 2 && n_iter >= 1 && W % 4 == 0 && nbk != 0 && abs(dstep) <= 16 &&
+                       ctx->opt[SMHIP_OPT_ITER_FUSED] != 0;
+    const size_t re = (size_t)W * d_count;                          // row of the private slab DSI
+    const size_t vol = re * (size_t)H;
+    const bool two_ends = px_ok && n_iter > 4 && d_count % 4 == 0;
+
+    smk::IterPxArgs g;
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.H = H; g.D = d_count;
+    g.force_slow = ctx->opt[SMHIP_OPT_TAP_SLOW] == 1;
+    g.pw.dstep = dstep;
+    g.pw.disp0 = -p->frame_diff_sign * p->disp_min + d_first * dstep;
+    g.pw.d_first = d_first;
+    g.pw.outside = smhip_match_outside(p);
+    auto fill_raw = [&](const smk::RawArgs &a) {
+        g.a.rn = a.rmn; g.a.rx = a.rmx ? a.rmx : a.rmn;
+        g.a.mn = a.mmn; g.a.mx = a.mmx ? a.mmx : a.mmn;
+        g.a.pitch = img_pitch; g.a.W = W; g.a.H = H; g.a.D = d_count;
+        g.a.disp0 = a.disp0; g.a.dstep = a.dstep; g.a.cutoff = a.cutoff; g.a.outside = a.outside;
+        g.a.bt_inline = 0;
+    };
+
+    if (px_ok && n_iter <= 4) {
+        // one kernel, no DSI: every workspace request before the first launch
+        const int lv = smk::iter_px_levels(smk::IPX_RAW, smk::IPX_KEYS);
+        (void)lv;
+        smk::RawArgs a;
+        rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
+        if (rc) return rc;
+        fill_raw(a);
+        return launch_iter_keys(ctx, n_iter, smk::IPX_RAW, nbk, a.sd != 0, g, d_keys);
+    }
+
+    // a private DSI of the slab (two buffers: the iterated passes ping-pong; membrane keeps the raw costs too)
+    const int n_buf = aggr_fn == 4 && n_iter > 0 ? 3 : 2;
+    void *ws = nullptr;
+    rc = ws_get(ctx, WS_TMP, vol * sizeof(float) * n_buf, &ws);
+    if (rc) return rc;
+    float *A = (float *)ws, *B = A + vol, *C0 = n_buf == 3 ? B + vol : nullptr;
+
+    if (two_ends) {
+        // K1 + (plain passes) + K2 iterations: the first K1 behind the raw costs, the last K2 in front of the WTA
+        int K1 = 4, K2 = 4;
+        if (n_iter < 8) { K1 = (n_iter + 1) / 2; K2 = n_iter - K1; }
+        const int mid = n_iter - K1 - K2;
+        smk::RawArgs a;
+        rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
+        if (rc) return rc;
+        fill_raw(a);
+        const int lv = smk::iter_px_levels(smk::IPX_RAW, smk::IPX_DSI), txi = smk::iter_px_tile_pixels(K1);
+        int tseg = tile_seglen(ctx, W, H, d_count);
+        if (vol * sizeof(float) >= ((size_t)1 << 30) && ctx->opt[SMHIP_OPT_TSEG] < 0 && H >= 512)
+            tseg = 256;
+        g.dst = A; g.row_elems = re; g.seglen = tseg;
+        const unsigned gz = (H + tseg - 1) / tseg;
+        if (gz > 65535 || (d_count + lv - 1) / lv > 65535)
+            return fail(SMHIP_EINVAL, "iterated fused path: grid too large");
+        if (!smk::launch_iter_px(K1, smk::IPX_RAW, smk::IPX_DSI, nbk, a.sd != 0, g, (W + txi - 1) / txi,
+                                 (d_count + lv - 1) / lv, gz, ctx->stream))
+            return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K1);
+        HIP_TRY(hipGetLastError());
+        float *cur = A;
+        if (mid > 0) {
+            int in_b = 0;
+            rc = smhip_convolve_14641_run(ctx, A, B, W, H, d_count, re, mid, &in_b);
+            if (rc) return rc;
+            cur = in_b ? B : A;
+        }
+        g.src = cur; g.dst = nullptr;
+        return launch_iter_keys(ctx, K2, smk::IPX_DSI, nbk, false, g, d_keys);
+    }
+
+    // the stage calls on the private DSI: raw costs of the slab, the aggregator, PadCosts + WTA -> keys
+    smhip_match_params ps = *p;
+    ps.disp_min = p->disp_min + d_first * p->disp_num;
+    ps.disp_n = d_count;
+    rc = smhip_raw_costs(ctx, d_ref, d_mtc, img_pitch, &ps, A, re);
+    if (rc) return rc;
+    float *cur = A;
+    if (n_iter > 0) {
+        int in_b = 0;
+        if (aggr_fn == 2) {
+            rc = smhip_convolve_14641_run(ctx, A, B, W, H, d_count, re, n_iter, &in_b);
+        } else {
+            const float bt = aggr_fn == 4 ? beta : 0.0f;            // eDiffusion forces beta = 0 (StcAggregate.cpp:305)
+            if (bt > 0.0f)
+                HIP_TRY(hipMemcpyAsync(C0, A, vol * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+            rc = smhip_diffusion_run(ctx, A, B, bt > 0.0f ? C0 : nullptr, W, H, d_count, re, lambda, bt, n_iter, &in_b);
+        }
+        if (rc) return rc;
+        cur = in_b ? B : A;
+    }
+    return smhip_pad_wta_keys(ctx, cur, re, p, d_first, d_count, d_keys);
 }
 
 int smhip_profile_begin(smhip_ctx *ctx, int max_calls)

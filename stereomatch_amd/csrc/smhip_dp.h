@@ -17,25 +17,11 @@
 #pragma once
 
 #include "smhip_opt.h"
+#include "smhip_dpp.h"
 
 namespace smk {
 
 constexpr int DP_OCC = -9999;                 // occLabel, :119
-constexpr int DPP_WAVE_SHL1 = 0x130;          // lane n <- lane n+1
-constexpr int DPP_WAVE_SHR1 = 0x138;          // lane n <- lane n-1
-
-// lane n <- v of lane n+1; lane 63 <- edge
-__device__ __forceinline__ float lane_from_above(float v, float edge)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), DPP_WAVE_SHL1,
-                                                      0xF, 0xF, false));
-}
-// lane n <- v of lane n-1; lane 0 <- edge
-__device__ __forceinline__ float lane_from_below(float v, float edge)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), DPP_WAVE_SHR1,
-                                                      0xF, 0xF, false));
-}
 __device__ __forceinline__ float lane_value(float v, int lane)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));

@@ -10,7 +10,7 @@ namespace smk {
 
 template <int WIN>
 void launch_fused_f_window(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev, bool sd,
-                           bool cut, hipStream_t stream, int policy, bool paired, long lds_min);
+                           bool cut, hipStream_t stream, int policy, bool paired, long lds_min, int one_wave);
 
 #ifdef SMK_F_WIN
 
@@ -18,10 +18,10 @@ namespace {
 
 template <int WIN, bool SD, bool CUT, int DS, int POL>
 void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                      hipStream_t stream, bool paired, long lds_min)
+                      hipStream_t stream, bool paired, long lds_min, int one_wave)
 {
     // 256-level chunks: two waves of two levels per lane; a 128-level slab: one wave
-    const int nw = Dp % 256 == 0 ? 2 : 1;
+    const int nw = (Dp % 256 == 0 && !one_wave) ? 2 : 1;     // one_wave: experiment / option a_nw
     const int cw = 128 * nw;
     int cbs = FUSED_F_NI * 64 * nw - WIN - cw;             // staged pixels per thread bounded by FUSED_F_NI
     if (cbs > 480) cbs = 480;
@@ -43,8 +43,8 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
             const long slots = 256 * per_cu, wgs = (long)a.H * (Dp / cw);
             return (double)wgs / (double)((wgs + slots - 1) / slots * slots);
         };
-        const long one_wave = fill(5) > fill(6) + 0.05 ? 31 * 1024 : 26 * 1024;
-        lds_min = a.W < 2560 ? 0 : nw == 1 ? one_wave : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);
+        const long one_wave_lds = fill(5) > fill(6) + 0.05 ? 31 * 1024 : 26 * 1024;
+        lds_min = a.W < 2560 ? 0 : nw == 1 ? one_wave_lds : (a.H >= 1280 && Dp <= 512 ? 54 * 1024 : 0);
     }
     // (four chunks, 8K x 1024: 22.4 against 22.1 ms without.  Rows shorter than 2560 pixels lose under a bound:
     // 2048x1536 3 %, 1280x1400 11 %, 800x1300x512 15 %, 640x4000x128 7 % -- profiles/r02_occupancy.log, last part.)
@@ -75,29 +75,29 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
 // kernels keep plain stores: non-temporal ones made the 4-band pass A 6 % slower for a 3 % faster pass B.)
 template <int WIN, bool SD, bool CUT, int DS>
 void launch_shape(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                  hipStream_t stream, int policy, bool paired, long lds_min)
+                  hipStream_t stream, int policy, bool paired, long lds_min, int one_wave)
 {
     if (policy < 0)
         policy = (size_t)a.W * a.H * Dp * sizeof(float) < ((size_t)4 << 30) ? 16 : 18;
     if (policy == 0)
-        launch_shape_pol<WIN, SD, CUT, DS, 0>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
+        launch_shape_pol<WIN, SD, CUT, DS, 0>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min, one_wave);
     else if (policy == 16)
-        launch_shape_pol<WIN, SD, CUT, DS, 16>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
+        launch_shape_pol<WIN, SD, CUT, DS, 16>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min, one_wave);
     else
-        launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min);
+        launch_shape_pol<WIN, SD, CUT, DS, 18>(a, T, tyshift, Dp, scale, keep_all, glev, stream, paired, lds_min, one_wave);
 }
 
 }  // namespace
 
 template <>
 void launch_fused_f_window<SMK_F_WIN>(const FusedA &a, float *T, int tyshift, int Dp, float scale, int keep_all, int glev,
-                                      bool sd, bool cut, hipStream_t stream, int policy, bool paired, long lds_min)
+                                      bool sd, bool cut, hipStream_t stream, int policy, bool paired, long lds_min, int one_wave)
 {
     constexpr int WIN = SMK_F_WIN;
 #define SMK_F(SD, CUT)                                                                             \
     do {                                                                                           \
-        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min); \
-        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min); \
+        if (a.dstep < 0) launch_shape<WIN, SD, CUT, -1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min, one_wave); \
+        else launch_shape<WIN, SD, CUT, 1>(a, T, tyshift, Dp, scale, keep_all, glev, stream, policy, paired, lds_min, one_wave); \
     } while (0)
     if (sd) { if (cut) SMK_F(true, true); else SMK_F(true, false); }
     else    { if (cut) SMK_F(false, true); else SMK_F(false, false); }
@@ -107,7 +107,7 @@ void launch_fused_f_window<SMK_F_WIN>(const FusedA &a, float *T, int tyshift, in
 #else   // the dispatcher
 
 bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
-                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min)
+                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min, int one_wave)
 {
     if (n_bands != 1 || (a.dstep != 1 && a.dstep != -1) || a.rn != a.rx || Dp % 128 != 0)
         return false;
@@ -121,11 +121,11 @@ bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift
         return false;
     const bool cut = a.cutoff < max_cost;                  // truncation can bite
     switch (window) {
-    case 3: launch_fused_f_window<3>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 5: launch_fused_f_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 7: launch_fused_f_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 9: launch_fused_f_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
-    case 11: launch_fused_f_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min); break;
+    case 3: launch_fused_f_window<3>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min, one_wave); break;
+    case 5: launch_fused_f_window<5>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min, one_wave); break;
+    case 7: launch_fused_f_window<7>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min, one_wave); break;
+    case 9: launch_fused_f_window<9>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min, one_wave); break;
+    case 11: launch_fused_f_window<11>(a, T, tyshift, Dp, scale, keep_all, glev, sd, cut, stream, policy, paired, lds_min, one_wave); break;
     default: return false;
     }
     return true;

@@ -14,6 +14,6 @@ namespace smk {
 // needs Dp == 128, glev == 4, keys out).  glev = levels per lane of the pass B that follows.  Returns false
 // (nothing launched) otherwise; the caller then takes fused_rawbox_h_lds_kernel.
 bool launch_fused_rawbox_h_f(const FusedA &a, int n_bands, float *T, int tyshift, int Dp, int window, float scale,
-                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min);
+                             int keep_all, int glev, bool sd, int max_cost, hipStream_t stream, int policy, bool paired, long lds_min, int one_wave);
 
 }  // namespace smk

@@ -1,0 +1,357 @@
+// smhip_iter_px.h -- the iterated binomial aggregation of exp4_aggr.txt with its neighbours fused in, "pixels on
+// lanes" (the layout of smhip_multi_px.h):
+//
+//     source  RAW : raw matching costs formed in the tile from the staged image rows (MatchLine,
+//                   StcRawCosts.cpp:130-218) -- the raw DSI is never written or read
+//             DSI : a resident DSI
+//     K <= 4 iterations of ConvolveSeparable 14641 (StcAggregate.cpp:280-289, Convolve.cpp:86-254)
+//     sink    DSI : the aggregated DSI
+//             KEYS: PadCosts (StcRawCosts.cpp:437-476) + OptWTA (StcOptimize.cpp:26-56) -> one 64-bit key per
+//                   pixel -- the aggregated DSI is never written or read
+//
+// RAW -> KEYS is aggr_iter <= 4 with no DSI traffic at all; for more iterations RAW -> DSI and DSI -> KEYS bracket
+// the plain multi-iteration passes (smhip_convolve_14641_run).
+//
+// Workgroup = 128 pixels (halo included) x LV levels, LV * 32 threads; thread = 4 consecutive pixels of one level;
+// horizontal neighbours by DPP from the adjacent lanes, vertical window in registers (static ring slots), one
+// barrier per row -- see smhip_multi_px.h.  With the KEYS sink a workgroup walks a segment of at most IPX_SEG rows
+// through SEVERAL level tiles (outer loop) and keeps the best (cost, level) of every pixel of the segment in LDS
+// (int32 ordered cost + uint16 level; tiles come in ascending level order, so a later tile wins only with a
+// strictly lower cost -- OptWTA's strict '<'); one store per pixel at the end.  A row leaves the level pipeline
+// through the transpose buffer `tout` (write before the row's barrier, read after it, one row late): for the DSI
+// sink the reader stores 4 levels of a pixel (16 bytes), for the KEYS sink it takes the minimum of the pixel's LV
+// levels: v_min_f32 over its four, a DPP butterfly over the pixel's LV / 4 lanes, lowest level equal to the minimum
+// by a second integer butterfly (as min_wta_tile_kernel).
+// RAW source: per row the reference pixels of the tile and the matching pixels its LV levels reach
+// (128 + (LV - 1) |dstep|) are staged in LDS as the packed words of smhip_fused.h (fetched one row ahead into
+// registers); the raw costs are non-negative integers, so the exact-product taps need no guard here.
+#pragma once
+
+#include "smhip_fused.h"
+#include "smhip_minwta.h"
+#include "smhip_multi_px.h"
+
+namespace smk {
+
+constexpr int IPX_SEG = 64;         // rows per segment with the KEYS sink (bounds the key arrays in LDS)
+constexpr int IPX_KSTRIDE = 65;     // keys per pixel in LDS: odd, the pixels a wave updates hit different banks
+enum { IPX_DSI = 0, IPX_RAW = 1, IPX_KEYS = 1 };
+
+struct IterPxArgs {
+    const float *src;               // DSI source
+    float *dst;                     // DSI sink
+    size_t row_elems;
+    int W, H, D;                    // width, rows, levels of the volume (slab) handled
+    int seglen, force_slow;
+    FusedA a;                       // RAW source
+    PadWtaArgs pw;                  // KEYS sink
+    int tiles_per_group;            // KEYS sink: level tiles a workgroup walks
+    size_t part_stride;             // KEYS sink: elements between the key images of the level groups (blockIdx.y)
+};
+
+// packed image words of the RAW source
+template <int NB> struct PxStage;
+template <> struct PxStage<2> {     // one band, point reference interval: the words of RowLds<2>
+    typedef uint32_t word;
+    static __device__ __forceinline__ word fetch_r(const FusedA &a, size_t ro, int x) { return RowLds<2>::ref_word(a.rn[ro + x]); }
+    static __device__ __forceinline__ word fetch_m(const FusedA &a, size_t ro, int x)
+    {
+        return RowLds<2>::match_word(a.mn[ro + x], a.mx[ro + x]);
+    }
+    template <bool SD> static __device__ __forceinline__ int gap(word r, word m)
+    {
+        const int e = (int)(__builtin_amdgcn_sad_u8(r, m, (uint32_t)-255) >> 1);
+        return SD ? e * e : e;
+    }
+};
+template <> struct PxStage<4> {     // four bands, intervals on both sides: the words of RowLds<4>
+    typedef uint2 word;             // (lower ends, upper ends)
+    static __device__ __forceinline__ word fetch_r(const FusedA &a, size_t ro, int x)
+    {
+        return make_uint2(*(const uint32_t *)(a.rn + ro + 4 * (size_t)x), *(const uint32_t *)(a.rx + ro + 4 * (size_t)x));
+    }
+    static __device__ __forceinline__ word fetch_m(const FusedA &a, size_t ro, int x)
+    {
+        return make_uint2(*(const uint32_t *)(a.mn + ro + 4 * (size_t)x), *(const uint32_t *)(a.mx + ro + 4 * (size_t)x));
+    }
+    template <bool SD> static __device__ __forceinline__ int gap(word r, word m)
+    {
+        int sum = 0;
+#pragma unroll
+        for (int s = 0; s < 32; s += 8) {
+            const int e = max(max((int)((m.x >> s) & 0xFF) - (int)((r.y >> s) & 0xFF),
+                                  (int)((r.x >> s) & 0xFF) - (int)((m.y >> s) & 0xFF)), 0);
+            sum += SD ? e * e : e;
+        }
+        return sum;
+    }
+};
+
+// minimum over each aligned group of QP lanes (QP = 4 or 8), delivered to all of them
+template <int QP> __device__ __forceinline__ float segq_allmin_f32(float x)
+{
+    if constexpr (QP == 8) {
+        return seg8_allmin_f32(x);
+    } else {
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+            : "+v"(x));
+        return x;
+    }
+}
+template <int QP> __device__ __forceinline__ int segq_allmin_u32(int x)
+{
+    if constexpr (QP == 8) {
+        return seg8_allmin_u32(x);
+    } else {
+        asm("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+            : "+v"(x));
+        return x;
+    }
+}
+
+template <int K, int LV, int SRC, int SINK, bool SD, int NB>
+__global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) void iter_px_kernel(const IterPxArgs g)
+{
+    typedef typename fvec<4>::type vec;
+    typedef typename PxStage<NB>::word word;
+    constexpr int HL = px_halo(K), TXI = px_txi(K), QP = LV / 4, NT = LV * 32;
+    constexpr bool RAW = SRC == IPX_RAW, KEYS = SINK == IPX_KEYS;
+    __shared__ __attribute__((aligned(16))) float tin[RAW ? 1 : 2][RAW ? 1 : LV][PX_STRIDE];
+    __shared__ __attribute__((aligned(16))) float tout[2][LV][PX_STRIDE];
+    __shared__ int kcost[KEYS ? TXI * IPX_KSTRIDE : 1];             // best ordered cost [pixel][row of the segment]
+    __shared__ unsigned short klev[KEYS ? TXI * IPX_KSTRIDE : 1];   // its level within the slab
+    __shared__ int guard;
+    extern __shared__ __attribute__((aligned(16))) uint8_t stage_raw[];     // RAW: 2 x (128 + NM) words
+    const int W = g.W, H = g.H, D = g.D;
+    const int t = threadIdx.x;
+    const int X0 = (int)blockIdx.x * TXI - HL;
+    const int y0 = (int)blockIdx.z * g.seglen, y1 = min(H, y0 + g.seglen);
+    // compute layout: level l of the tile, pixels X0 + 4 q .. + 3
+    const int l = t >> 5, q4 = t & 31;
+    const int xb = X0 + 4 * q4;
+    const bool left_edge = xb == 0, right_edge = xb + 3 == W - 1;
+    // DSI layout: pixel lp of the tile, levels 4 lq .. + 3 of the tile
+    const int lp = t / QP, lq = t % QP;
+    const bool has_out = lp >= HL && lp < PX_TXT - HL && X0 + lp < W;
+    // RAW: staged words
+    const int adstep = g.a.dstep < 0 ? -g.a.dstep : g.a.dstep;
+    const int NM = PX_TXT + (LV - 1) * adstep, n_items = PX_TXT + NM;
+    word *sr[2], *sm[2];
+    sr[0] = (word *)stage_raw; sm[0] = sr[0] + PX_TXT; sr[1] = sm[0] + NM; sm[1] = sr[1] + PX_TXT;
+
+    if (KEYS)
+        for (int i = t; i < TXI * IPX_KSTRIDE; i += NT)
+            kcost[i] = 0x7FFFFFFF;
+    if (t == 0)
+        guard = g.force_slow;
+    const vec zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int Rlo = y0 - 2 * K, Rin = y1 - 1 + 2 * K, Rhi = Rin + 1;
+
+    // ---- per level tile ------------------------------------------------------------------------
+    int k0 = 0;                     // first level of the tile
+    size_t lcol = 0;                // DSI source / sink: this thread's column
+    bool lact = false;              // DSI layout: its four levels exist
+    bool padded[4] = {false, false, false, false}, dead[4] = {false, false, false, false};
+    int dl = 0, mslot = 0, M0 = 0;  // RAW: this thread's disparity, its first matching slot, first staged matching pixel
+    vec ring[K][5];                 // level j: horizontally filtered rows n-4 .. n, slot = row mod 5
+    vec nxt = zero, res = zero;
+    word pre[2];                    // RAW: the words this thread stages for the next row
+    bool slow = false;
+
+    auto tap = [&](vec s0, vec s1, vec s2, vec s3, vec s4) -> vec {
+        if (!RAW && slow)
+            return vtap5<4>(s0, s1, s2, s3, s4);
+        return vtap5_pow2<4>(s0, s1, s2, s3, s4);
+    };
+    auto htap = [&](vec v, auto fast) -> vec {
+        float l2 = lane_from_below(v[2], v[0]), l3 = lane_from_below(v[3], v[0]);
+        float r0 = lane_from_above(v[0], v[3]), r1 = lane_from_above(v[1], v[3]);
+        if (left_edge)
+            l2 = l3 = v[0];
+        if (right_edge)
+            r0 = r1 = v[3];
+        const float w[8] = {l2, l3, v[0], v[1], v[2], v[3], r0, r1};
+        vec h;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (RAW || decltype(fast)::value || !slow)
+                h[e] = tap5_pow2(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
+            else
+                h[e] = tap5(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
+        }
+        return h;
+    };
+    auto fetch_row = [&](int R) {   // RAW: words of row R into registers
+        const size_t ro = (size_t)clampi(R, H) * g.a.pitch;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int it = t + i * NT;
+            if (it < PX_TXT)
+                pre[i] = PxStage<NB>::fetch_r(g.a, ro, clampi(X0 + it, W));
+            else if (it < n_items)
+                pre[i] = PxStage<NB>::fetch_m(g.a, ro, clampi(M0 + it - PX_TXT, W));
+        }
+    };
+    auto step = [&](auto rr, const int R) {
+        constexpr int RR = decltype(rr)::value;
+        const int p = (RR & 1) ^ (((R - Rlo) / 5) & 1);     // parity of R - Rlo
+        if constexpr (RAW) {
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                const int it = t + i * NT;
+                if (it < PX_TXT)
+                    sr[p][it] = pre[i];
+                else if (it < n_items)
+                    sm[p][it - PX_TXT] = pre[i];
+            }
+            if (R + 1 <= Rin)
+                fetch_row(R + 1);
+        } else {
+            if (!slow && tap_guard_bad(nxt))
+                guard = 1;
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+                tin[p][4 * lq + e][lp] = nxt[e];
+            if (lact && R + 1 <= Rin && R + 1 >= 0 && R + 1 < H)
+                nxt = vload<4>(g.src + (size_t)(R + 1) * g.row_elems + lcol);
+        }
+        *(vec *)&tout[p][l][4 * q4] = res;      // the row finished at the step before
+        __syncthreads();
+        if (!RAW && !slow)                      // the guard of this row's inputs was set before the barrier
+            slow = __builtin_amdgcn_readfirstlane(guard) != 0;
+        const int qs = R - 1 - 2 * K;           // row in tout
+        if (qs >= y0 && qs < y1) {
+            if constexpr (KEYS) {
+                // PadCosts, then the lowest cost of the pixel's LV levels and the lowest level holding it
+                float c[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    c[e] = padded[e] ? g.pw.outside : tout[p][4 * lq + e][lp];
+                    c[e] = dead[e] ? __builtin_inff() : c[e];       // levels beyond the slab
+                }
+                float bc = fmin_hw(fmin_hw(c[0], c[1]), fmin_hw(c[2], c[3]));
+                const bool live = has_out && lact;
+                bc = live ? bc : __builtin_inff();
+                const float mm = segq_allmin_f32<QP>(bc);
+                const int lev = k0 + 4 * lq;
+                int cand = 0x7FFFFFFF;
+#pragma unroll
+                for (int e = 3; e >= 0; e--)
+                    cand = c[e] == mm ? lev + e : cand;
+                cand = live ? cand : 0x7FFFFFFF;
+                cand = segq_allmin_u32<QP>(cand);
+                if (lq == 0 && has_out) {
+                    const int idx = (lp - HL) * IPX_KSTRIDE + (qs - y0), oc = ordered_bits(mm);
+                    if (oc < kcost[idx]) {
+                        kcost[idx] = oc;
+                        klev[idx] = (unsigned short)cand;
+                    }
+                }
+            } else {
+                if (has_out && lact) {
+                    vec o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++)
+                        o[e] = tout[p][4 * lq + e][lp];
+                    vstore<4>(g.dst + (size_t)qs * g.row_elems + lcol, o);
+                }
+            }
+        }
+        vec val;                                // level 0, row R
+        if constexpr (RAW) {
+            // MatchLine (StcRawCosts.cpp:152-198) for this thread's four reference pixels at its level
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int c = min(PxStage<NB>::template gap<SD>(sr[p][4 * q4 + e], sm[p][mslot + e]), g.a.cutoff);
+                val[e] = (unsigned)(xb + e + dl) >= (unsigned)W ? (float)g.a.outside : (float)c;
+            }
+        } else {
+            val = *(const vec *)&tin[p][l][4 * q4];
+        }
+        if ((RAW || !slow) && R - 2 * (K - 1) >= 1 && R <= H - 1) {
+            // every level's row lies inside the image and the exact-product taps apply: one basic block
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int s = (RR + 10 * K - 2 * j) % 5;
+                ring[j][s] = htap(val, icst<1>{});
+                val = vtap5_pow2<4>(ring[j][(s + 1) % 5], ring[j][(s + 2) % 5], ring[j][(s + 3) % 5],
+                                    ring[j][(s + 4) % 5], ring[j][s]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int n = R - 2 * j;        // row of level j arriving now
+                const int s = (RR + 10 * K - 2 * j) % 5;    // its ring slot; rows n-4 .. n-1 sit in s+1 .. s+4 (mod 5)
+                if (n <= H - 1) {               // rows below the image replicate the last row
+                    ring[j][s] = htap(val, icst<0>{});
+                    if (n == 0)                 // rows above the image replicate row 0
+                        ring[j][(s + 3) % 5] = ring[j][(s + 4) % 5] = ring[j][s];
+                } else {
+                    ring[j][s] = ring[j][(s + 4) % 5];
+                }
+                val = tap(ring[j][(s + 1) % 5], ring[j][(s + 2) % 5], ring[j][(s + 3) % 5], ring[j][(s + 4) % 5],
+                          ring[j][s]);          // level j+1, row n-2
+            }
+        }
+        res = val;                              // output row R - 2 K
+    };
+
+    const int n_tiles = KEYS ? g.tiles_per_group : 1;
+    for (int tile = 0; tile < n_tiles; tile++) {
+        k0 = (KEYS ? (int)blockIdx.y * g.tiles_per_group + tile : (int)blockIdx.y) * LV;
+        if (k0 >= D)
+            break;
+        lact = k0 + 4 * lq < D;
+        lcol = (size_t)clampi(X0 + lp, W) * D + (size_t)min(k0 + 4 * lq, D - 4);
+        if constexpr (KEYS) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                padded[e] = (unsigned)(X0 + lp + g.pw.disp0 + (k0 + 4 * lq + e) * g.pw.dstep) >= (unsigned)W;
+                dead[e] = k0 + 4 * lq + e >= D;
+            }
+        }
+        if constexpr (RAW) {
+            const int d_lo = g.a.disp0 + k0 * g.a.dstep + min(0, (LV - 1) * g.a.dstep);
+            M0 = X0 + d_lo;
+            dl = g.a.disp0 + (k0 + l) * g.a.dstep;
+            mslot = 4 * q4 + dl - d_lo;
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++)
+#pragma unroll
+            for (int i = 0; i < 5; i++)
+                ring[j][i] = zero;
+        nxt = zero;
+        res = zero;
+        if constexpr (RAW) {
+            fetch_row(Rlo);
+        } else {
+            if (lact && Rlo >= 0 && Rlo < H)
+                nxt = vload<4>(g.src + (size_t)Rlo * g.row_elems + lcol);
+        }
+        __syncthreads();            // the buffers of the level tile before are free (and kcost / guard are set)
+        for (int Rb = Rlo; Rb <= Rhi; Rb += 5) {
+            step(icst<0>{}, Rb);
+            if (Rb + 1 <= Rhi) step(icst<1>{}, Rb + 1);
+            if (Rb + 2 <= Rhi) step(icst<2>{}, Rb + 2);
+            if (Rb + 3 <= Rhi) step(icst<3>{}, Rb + 3);
+            if (Rb + 4 <= Rhi) step(icst<4>{}, Rb + 4);
+        }
+    }
+    if constexpr (KEYS) {
+        __syncthreads();
+        const int rows = y1 - y0;
+        long long *keys = g.pw.keys + (size_t)blockIdx.y * g.part_stride;
+        for (int i = t; i < TXI * IPX_SEG; i += NT) {   // column-major keys: a pixel's rows are contiguous
+            const int px = i / IPX_SEG, r = i % IPX_SEG;
+            const int x = X0 + HL + px;
+            if (x < W && r < rows)
+                keys[(size_t)x * H + y0 + r] = make_key(kcost[px * IPX_KSTRIDE + r],
+                                                        g.pw.d_first + (int)klev[px * IPX_KSTRIDE + r]);
+        }
+    }
+}
+
+}  // namespace smk

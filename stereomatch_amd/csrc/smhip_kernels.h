@@ -16,6 +16,13 @@
 
 #include "smhip_fused_defs.h"
 
+// The non-template kernels below are defined in a header: a second translation unit that includes it (for the
+// device helpers) defines SMK_GLOBAL as `static __global__ __attribute__((unused))` so that the library holds one
+// external definition of each.
+#ifndef SMK_GLOBAL
+#define SMK_GLOBAL __global__
+#endif
+
 namespace smk {
 
 // Parameters of the raw-cost evaluation, shared by the stand-alone and fused kernels.
@@ -56,7 +63,7 @@ __device__ __forceinline__ int raw_cost(const RawArgs &a, const uint8_t *rmn, co
 }
 
 // BirchfieldTomasiMinMax, StcRawCosts.cpp:107-128: one thread per (y, x, band).
-__global__ void bt_minmax_kernel(const uint8_t *img, uint8_t *mn, uint8_t *mx, size_t pitch,
+SMK_GLOBAL void bt_minmax_kernel(const uint8_t *img, uint8_t *mn, uint8_t *mx, size_t pitch,
                                  int W, int H, int nb)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // x*nb + band
@@ -75,7 +82,7 @@ __global__ void bt_minmax_kernel(const uint8_t *img, uint8_t *mn, uint8_t *mx, s
 }
 
 // RawCostsCPU, StcRawCosts.cpp:370-417 (den = 1): one thread per DSI element.
-__global__ void raw_costs_kernel(RawArgs a, float *cost, size_t row_elems)
+SMK_GLOBAL void raw_costs_kernel(RawArgs a, float *cost, size_t row_elems)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;   // x*D + k
     int y = blockIdx.y;
@@ -103,7 +110,7 @@ __device__ __forceinline__ int border_index(int i, int len, int mode)
 }
 
 // the same running sums with the reference's other border modes (smhip_box_filter_border); not a hot path
-__global__ void box_lines_border_kernel(const float *src, float *dst, long n_chains, int n_sums,
+SMK_GLOBAL void box_lines_border_kernel(const float *src, float *dst, long n_chains, int n_sums,
                                         size_t outer_stride, size_t stride, int len, int w, float scale, int mode)
 {
     long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,7 +133,7 @@ __global__ void box_lines_border_kernel(const float *src, float *dst, long n_cha
     }
 }
 
-__global__ void box_lines_kernel(const float *src, float *dst, long n_chains, int n_sums,
+SMK_GLOBAL void box_lines_kernel(const float *src, float *dst, long n_chains, int n_sums,
                                  size_t outer_stride, size_t stride, int len, int w, float scale)
 {
     long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,7 +160,7 @@ __global__ void box_lines_kernel(const float *src, float *dst, long n_chains, in
 // MinMaxFilter, MinFilter.cpp:122-202 (min, replicate): o = min over [x+pl+1, x+pr].
 // One thread per output element; `axis_stride` is the element spacing along the filtered
 // axis, `pos`/`len` the coordinate along it.
-__global__ void min_h_kernel(const float *src, float *dst, int W, int D, size_t row_elems, int w)
+SMK_GLOBAL void min_h_kernel(const float *src, float *dst, int W, int D, size_t row_elems, int w)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -170,7 +177,7 @@ __global__ void min_h_kernel(const float *src, float *dst, int W, int D, size_t 
     dst[(size_t)y * row_elems + i] = m;
 }
 
-__global__ void min_v_kernel(const float *src, float *dst, int WD, int H, size_t row_elems, int w)
+SMK_GLOBAL void min_v_kernel(const float *src, float *dst, int WD, int H, size_t row_elems, int w)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -197,7 +204,7 @@ __device__ __forceinline__ float tap5(float s0, float s1, float s2, float s3, fl
     return acc;
 }
 
-__global__ void binom_h_kernel(const float *src, float *dst, int W, int D, size_t row_elems)
+SMK_GLOBAL void binom_h_kernel(const float *src, float *dst, int W, int D, size_t row_elems)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -211,7 +218,7 @@ __global__ void binom_h_kernel(const float *src, float *dst, int W, int D, size_
              row[(size_t)clampi(x + 2, W) * D]);
 }
 
-__global__ void binom_v_kernel(const float *src, float *dst, int WD, int H, size_t row_elems)
+SMK_GLOBAL void binom_v_kernel(const float *src, float *dst, int WD, int H, size_t row_elems)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -224,7 +231,7 @@ __global__ void binom_v_kernel(const float *src, float *dst, int WD, int H, size
 }
 
 // AggrDiffusion, StcDiffusion.cpp:75-136.
-__global__ void diffusion_kernel(const float *src, float *dst, const float *cost0, int W, int D,
+SMK_GLOBAL void diffusion_kernel(const float *src, float *dst, const float *cost0, int W, int D,
                                  int H, size_t row_elems, float lambda, float a, float lb,
                                  int membrane)
 {
@@ -246,7 +253,7 @@ __global__ void diffusion_kernel(const float *src, float *dst, const float *cost
 // PadCosts, StcRawCosts.cpp:437-476 (den = 1): C[y][i][k] = outside where i + disp(k) is
 // off the line.  One thread per (y, k, j): candidate pixels j from the left end and
 // W-1-j from the right end.
-__global__ void pad_costs_kernel(float *cost, size_t row_elems, int W, int D, int disp0, int dstep,
+SMK_GLOBAL void pad_costs_kernel(float *cost, size_t row_elems, int W, int D, int disp0, int dstep,
                                  int maxpad, float outside)
 {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -297,7 +304,7 @@ __device__ __forceinline__ void seg_min(int &s, int &d)
 
 // OptWTA, StcOptimize.cpp:26-56.  One wave per pixel (lanes stride over d), wave-level
 // lexicographic (cost, d) min => first minimum wins exactly as the serial strict '<' scan.
-__global__ void wta_wave_kernel(const float *cost, int W, int H, int D, size_t row_elems,
+SMK_GLOBAL void wta_wave_kernel(const float *cost, int W, int H, int D, size_t row_elems,
                                 int32_t *disp, float *best)
 {
     int lane = threadIdx.x & 63;
@@ -321,7 +328,7 @@ __global__ void wta_wave_kernel(const float *cost, int W, int H, int D, size_t r
 }
 
 // Small D: one thread per pixel, serial scan.
-__global__ void wta_thread_kernel(const float *cost, int W, int H, int D, size_t row_elems,
+SMK_GLOBAL void wta_thread_kernel(const float *cost, int W, int H, int D, size_t row_elems,
                                   int32_t *disp, float *best)
 {
     long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,7 +346,7 @@ __global__ void wta_thread_kernel(const float *cost, int W, int H, int D, size_t
     if (best) best[p] = bc;
 }
 
-__global__ void keys_min_kernel(const long long *part, int n_part, size_t n, long long *out)
+SMK_GLOBAL void keys_min_kernel(const long long *part, int n_part, size_t n, long long *out)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -358,7 +365,7 @@ __global__ void keys_min_kernel(const long long *part, int n_part, size_t n, lon
 // One thread per (y, k) chain, k on lanes.  The raw costs entering and leaving the window
 // are recomputed from the image lines (integers, exact in float), so the raw DSI is never
 // written: HBM traffic = one write of T.
-__global__ void fused_rawbox_h_kernel(RawArgs a, float *T, size_t trow, int Dp, int w, float scale)
+SMK_GLOBAL void fused_rawbox_h_kernel(RawArgs a, float *T, size_t trow, int Dp, int w, float scale)
 {
     long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= (long)a.H * Dp)
@@ -389,7 +396,7 @@ __global__ void fused_rawbox_h_kernel(RawArgs a, float *T, size_t trow, int Dp, 
 // aligned lane segment of a wave and min-reduce (ordered cost, d) with shuffles.  Keys are
 // written column-major (pixel (x,y) at x*H + y), like the wide-slab kernel of smhip_fused_b.h.
 template <int SEG>
-__global__ void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H, int D, int w,
+SMK_GLOBAL void fused_boxv_wta_kernel(const float *T, size_t trow, int W, int H, int D, int w,
                                       float scale, int disp0, int dstep, float outside,
                                       int d_first, long long *keys)
 {

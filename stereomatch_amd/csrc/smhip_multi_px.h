@@ -20,7 +20,7 @@
 #pragma once
 
 #include "smhip_multi.h"
-#include "smhip_dp.h"
+#include "smhip_dpp.h"
 
 namespace smk {
 

@@ -110,6 +110,14 @@ class StereoMatcher(StereoParameters):
                 and not self.aggr_subpixel and not self.aggr_collapse
                 and not self.eval_match_quality and self.m_disp_den == 1)
 
+    def _iter_fusable(self):
+        # binomial iterations + WTA and nobody needs the DSI afterwards: smhip_fused_iter_wta_keys (aggr_iter <= 4
+        # as one kernel that moves no DSI, more between its raw-cost and its WTA end)
+        return (self.allow_fused and self.aggr_fn == eBinomial and self.aggr_iter >= 1
+                and self.aggr_minfilter <= 1 and self.opt_fn == eWTA and not self.refine_subpix
+                and not self.aggr_subpixel and not self.aggr_collapse
+                and not self.eval_match_quality and self.m_disp_den == 1 and self.m_params.disp_n <= 65535)
+
     def _box_dsi_fusable(self):
         # RawCosts + one AggrBox as smhip_fused_box_dsi (12 instead of 20 bytes per voxel)
         p = self.m_params
@@ -148,6 +156,14 @@ class StereoMatcher(StereoParameters):
         if self.used_fused:
             c.fused_box_wta(self.d_ref, self.d_mtc, self.m_pitch, self.m_params,
                             self.aggr_window_size, self.d_disp, self.d_best)
+            disp = c.download(self.d_disp, (h, w), np.int32)
+            self.m_float_disparity = self._scale_and_offset(disp)
+        elif self._iter_fusable():
+            self.used_fused = True
+            keys = self._buf("keys", w * h * 8)
+            c.fused_iter_wta_keys(self.d_ref, self.d_mtc, self.m_pitch, self.m_params, self.aggr_fn, self.aggr_iter,
+                                  0, self.m_params.disp_n, keys, self.diff_lambda, self.diff_beta)
+            c.keys_decode(keys, w, h, self.d_disp, self.d_best)
             disp = c.download(self.d_disp, (h, w), np.int32)
             self.m_float_disparity = self._scale_and_offset(disp)
         else:
@@ -193,6 +209,11 @@ class StereoMatcher(StereoParameters):
         if self.used_fused:
             c.fused_box_wta_keys(self.d_ref, self.d_mtc, self.m_pitch, whole, self.aggr_window_size,
                                  d_first, d_count, keys)
+            return keys
+        if self._iter_fusable():
+            self.used_fused = True
+            c.fused_iter_wta_keys(self.d_ref, self.d_mtc, self.m_pitch, whole, self.aggr_fn, self.aggr_iter,
+                                  d_first, d_count, keys, self.diff_lambda, self.diff_beta)
             return keys
         self.m_params = capi.match_params(
             w, h, nb, d_count, disp_min=self.disp_min + d_first * self.m_disp_num, disp_num=self.m_disp_num,

@@ -47,6 +47,35 @@ def test_config4_iterated_aggregation_full_size(gpu_ctx, oracle):
         util.assert_bit_equal(got, want[halo:halo + (y1 - y0)], name)
 
 
+@pytest.mark.parametrize("n_iter", [4, 8])
+def test_config4_fused_iterated_path_full_size(gpu_ctx, oracle, n_iter):
+    """3840x2160, D = 512 (config 4) through smhip_fused_iter_wta_keys: raw costs -> 4 / 8 binomial iterations ->
+    PadCosts -> WTA keys without a raw or an aggregated DSI (8: between the raw-cost and the WTA end kernels), one
+    call per 256 levels as a GPU's share would be; three bands of rows (top border, a segment boundary of the
+    keys kernel, bottom border) against the oracle run on the matching band of the input plus the 2-rows-per-
+    iteration halo."""
+    W, H, D = 3840, 2160, 512
+    left, right, _ = synth.scene_pair(W, H, 256)
+    p = capi.match_params(W, H, 1, D, match_fn=1, match_interval=1)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    keys = gpu_ctx.alloc(W * H * 8)
+    k = None
+    for d0 in (0, 256):
+        gpu_ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, 2, n_iter, d0, 256, keys)
+        part = gpu_ctx.download(keys, (W, H), np.int64)
+        k = part if k is None else np.minimum(k, part)
+    halo = 2 * n_iter
+    for y0, y1 in ((0, 6), (1020, 1030), (H - 5, H)):
+        b0, b1 = max(0, y0 - halo), min(H, y1 + halo)
+        po = oracle.make_params(W, b1 - b0, 1, disp_max=D - 1, match_fn=1, match_interval=1, aggr_fn=2,
+                                aggr_iter=n_iter)
+        wd, wb = oracle.compute_correspondence(_band(left, b0, b1), _band(right, b0, b1), po)[:2]
+        gd, gb = sharding.decode_keys(np.ascontiguousarray(k[:, y0:y1].T))
+        assert np.array_equal(gd, wd[y0 - b0:y1 - b0]), "rows %d..%d: disparity" % (y0, y1)
+        util.assert_bit_equal(gb, wb[y0 - b0:y1 - b0], "rows %d..%d: best cost" % (y0, y1))
+    assert len(np.unique(k & 0xFFFFFFFF)) > 100
+
+
 def test_config5_slab_full_size(gpu_ctx, oracle):
     """7680x4320, one 128-level slab (levels 512..639 of D = 1024: config 5's per-GPU share) through
     the fused path; the top 24 rows against the oracle (the vertical running sum starts at row 0)."""
