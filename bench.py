@@ -67,6 +67,10 @@ def main():
                     help="rehearsal / test: rank 0 compares EVERY decoded frame with the CPU oracle")
     ap.add_argument("--max-call-levels", type=int, default=MAX_CALL_LEVELS,
                     help="N > 1: levels per fused call (tests lower it to exercise the local key merge)")
+    ap.add_argument("--collective", choices=("allreduce", "reduce_scatter"), default="allreduce",
+                    help="N > 1: how the per-pixel keys of the ranks are merged -- one int64 MIN all-reduce (every "
+                         "rank ends with the merged keys and decodes them), or a MIN reduce-scatter whose chunks are "
+                         "gathered and decoded on rank 0 only (half the xGMI traffic)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")
     args = ap.parse_args()
@@ -136,9 +140,11 @@ def main():
 
     t_ref = torch.from_numpy(left.reshape(H, W * b)).to(dev)
     t_mtc = torch.from_numpy(right.reshape(H, W * b)).to(dev)
-    keys = torch.empty((W, H), dtype=torch.int64, device=dev)   # column-major key image
-    keys2 = torch.empty_like(keys) if multi else None
-    keys_part = torch.empty_like(keys) if Dg > max_call and multi else None
+    # column-major key image; for the reduce-scatter a flat buffer padded to a multiple of the ranks (the padding
+    # keeps the largest key: the kernels write the first W * H elements only)
+    n_keys = sharding.padded_key_count(W * H, world) if multi else W * H
+    keys = torch.full((n_keys,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+    keys2 = torch.full_like(keys, torch.iinfo(torch.int64).max) if multi else None
     disp = torch.empty((H, W), dtype=torch.int32, device=dev)
     best = torch.empty((H, W), dtype=torch.float32, device=dev)
     p = capi.match_params(W, H, b, D, match_fn=1, match_interval=1, match_max=1000)
@@ -159,14 +165,16 @@ def main():
         if True:
             for i, s0 in enumerate(range(d_first, d_first + Dg, max_call)):
                 n = min(max_call, d_first + Dg - s0)
-                out = buf if i == 0 else keys_part
-                ctx.fused_box_wta_keys(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, s0, n, out.data_ptr())
-                if i > 0:
-                    torch.minimum(buf, keys_part, out=buf)      # keys of one rank's calls merge like those of ranks
+                # the keys of one rank's calls merge like those of ranks: from the second call on pass B stores
+                # min(old key, new key) (smhip_fused_box_wta_keys_merge) -- no pass over two key images
+                fn = ctx.fused_box_wta_keys if i == 0 else ctx.fused_box_wta_keys_merge
+                fn(t_ref.data_ptr(), t_mtc.data_ptr(), W * b, p, win, s0, n, buf.data_ptr())
         ev1.record()
         produce_events.append((ev0, ev1))
 
     def consume(buf, _frame):
+        if buf is None:             # reduce-scatter mode: the merged keys exist on rank 0 only
+            return
         ctx.keys_decode(buf.data_ptr(), W, H, disp.data_ptr(), best.data_ptr())
         if want is not None:
             got_d, got_b = disp.cpu().numpy(), best.cpu().numpy()
@@ -176,7 +184,8 @@ def main():
 
     # N > 1: the one exchange step (int64 MIN all-reduce over xGMI) overlaps the next frame
     pipe = sharding.KeyReducePipeline([keys, keys2], produce, consume, force_collective=(world == 1),
-                                      host_staging=(args.backend != "nccl")) if multi else None
+                                      host_staging=(args.backend != "nccl"),
+                                      collective=args.collective) if multi else None
 
     trace = bool(os.environ.get("BENCH_TRACE"))
 
@@ -293,13 +302,14 @@ def main():
 
         if sharded:
             workload = ("fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, D=%d over %d GPUs by "
-                        "disparity slab (%d levels per GPU in calls of <= %d), int64-MIN %s all-reduce of the keys" % (
+                        "disparity slab (%d levels per GPU in calls of <= %d), int64-MIN %s %s of the keys" % (
                             win, win, W, H, b, D, world, Dg, max_call,
-                            "RCCL" if args.backend == "nccl" else args.backend + " (host-staged)"))
+                            "RCCL" if args.backend == "nccl" else args.backend + " (host-staged)",
+                            "all-reduce" if args.collective == "allreduce" else "reduce-scatter + gather on rank 0"))
         else:
             workload = "fused BT-SAD raw cost + %dx%d box + PadCosts + WTA, %dx%d, b=%d, D=%d (%d levels per GPU%s)" % (
                 win, win, W, H, b, D, Dg,
-                ", int64-MIN %s all-reduce of keys" % ("RCCL" if args.backend == "nccl" else args.backend)
+                ", int64-MIN %s %s of keys" % ("RCCL" if args.backend == "nccl" else args.backend, args.collective)
                 if multi else "")
         out = {
             "metric": "cost-volume throughput (G pixel*disparity/s)",
@@ -313,7 +323,8 @@ def main():
                 "width": W, "height": H, "bands": b, "disp_total": D, "disp_per_gpu": Dg,
                 "window": win, "match_fn": "AD", "match_interval": 1, "match_max": 1000,
                 "parallelism": "disparity slabs x%d" % world,
-                "collective_backend": (args.backend if multi else None)},
+                "collective_backend": (args.backend if multi else None),
+                "collective": (args.collective if multi else None)},
             "roofline": {k: dominant[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
             "roofline_kernel": dominant["kernel"],
             "traffic_source": traffic_source,
@@ -323,7 +334,12 @@ def main():
         if multi:
             out["per_rank_compute_ms"] = per_rank_compute
             out["exposed_collective_ms"] = round(ms_step - max(per_rank_compute), 4)
-            out["collective_bytes_per_step"] = W * H * 8
+            # bytes a rank sends per frame: ring all-reduce 2 (N-1)/N of the key image; reduce-scatter (N-1)/N
+            # plus its 1/N chunk to the root
+            kb = n_keys * 8
+            out["collective_bytes_per_step"] = kb
+            out["collective_bytes_sent_per_rank"] = int(
+                2 * kb * (world - 1) / world if args.collective == "allreduce" else kb * (world - 1) / world + kb / world)
         if args.check_oracle:
             out["frames_checked_vs_oracle"] = frames_checked[0]
         if extra is not None:

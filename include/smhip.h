@@ -89,7 +89,7 @@ enum smhip_option {
     SMHIP_OPT_MULTI_PX,       /* multi-iteration binomial pass with pixels on lanes (width % 4 == 0): 16 / 32 levels per workgroup; 0 / default: off */
     SMHIP_OPT_ITER_FUSED,     /* smhip_fused_iter_wta_keys: 0 = always the stage calls on a private DSI (tests) */
     SMHIP_OPT_ITER_GROUPS,    /* smhip_fused_iter_wta_keys: level groups (workgroups along the levels) of the keys kernels, 1..16 */
-    SMHIP_OPT_A_NW,           /* 1: float-lane pass A in one-wave workgroups (128 levels each) also on 256-level chunks */
+    SMHIP_OPT_A_NW,           /* float-lane pass A on 256-level chunks: 0 = two-wave workgroups, 1 = one-wave workgroups of 128 levels, 4 = one wave of four levels per lane (window 9) */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);
@@ -270,6 +270,15 @@ int smhip_opt_dp(smhip_ctx *ctx, const float *d_cost, int w, int h, int n_bands,
 int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
                              size_t img_pitch, const smhip_match_params *p, int window,
                              int d_first, int d_count, int64_t *d_keys);
+/* smhip_fused_box_wta_keys for a caller that walks a level range in several calls (a rank's share of a sharded
+ * volume in calls of bounded workspace): d_keys already holds the keys of other levels and receives the
+ * element-wise minimum with this call's -- the merge OptWTA's scan makes between levels
+ * (StcOptimize.cpp:43-52), folded into the store of pass B instead of a separate pass over two key images.
+ * The first call of a frame is smhip_fused_box_wta_keys. */
+int smhip_fused_box_wta_keys_merge(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                                   size_t img_pitch, const smhip_match_params *p, int window,
+                                   int d_first, int d_count, int64_t *d_keys);
+
 /* The first half of the above with the aggregated DSI as the result: RawCosts + one AggrBox of
  * levels [d_first, d_first + d_count) written to d_cost[h][row_elems] (d_count levels per pixel,
  * NOT yet padded: AggrMin / PadCosts / ... follow as in StcAggregate.cpp:351-400).  12 bytes per

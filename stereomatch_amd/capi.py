@@ -26,7 +26,7 @@ SYMBOLS = [
     "smhip_diffusion_run", "smhip_convolve_14641_run",
     "smhip_fused_box_dsi", "smhip_min_pad_wta_keys", "smhip_preprocess_blur",
     "smhip_opt_so", "smhip_bayesian_iter", "smhip_opt_dp", "smhip_bayesian_run", "smhip_pad_wta_keys",
-    "smhip_last_pass_a_kernel", "smhip_fused_iter_wta_keys",
+    "smhip_last_pass_a_kernel", "smhip_fused_iter_wta_keys", "smhip_fused_box_wta_keys_merge",
 ]
 
 
@@ -128,6 +128,7 @@ def load():
     L.smhip_pad_costs.argtypes = [vp, vp, sz, pp]
     L.smhip_wta.argtypes = [vp, vp, ci, ci, ci, sz, vp, vp]
     L.smhip_fused_box_wta_keys.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
+    L.smhip_fused_box_wta_keys_merge.argtypes = [vp, vp, vp, sz, pp, ci, ci, ci, vp]
     L.smhip_keys_decode.argtypes = [vp, vp, ci, ci, vp, vp]
     L.smhip_fused_box_wta.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
     L.smhip_fused_box_wta_noalloc.argtypes = [vp, vp, vp, sz, pp, ci, vp, vp]
@@ -341,6 +342,11 @@ class Context:
         self._chk(self.L.smhip_fused_box_wta_keys(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
                                                   C.byref(p), window, d_first, d_count,
                                                   _ptr(d_keys)))
+
+    def fused_box_wta_keys_merge(self, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_keys):
+        """As fused_box_wta_keys, but d_keys receives min(d_keys, this call's keys)."""
+        self._chk(self.L.smhip_fused_box_wta_keys_merge(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch,
+                                                        C.byref(p), window, d_first, d_count, _ptr(d_keys)))
 
     def fused_box_dsi(self, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_cost, row_elems):
         self._chk(self.L.smhip_fused_box_dsi(self.h, _ptr(d_ref), _ptr(d_mtc), img_pitch, C.byref(p),

@@ -1380,7 +1380,7 @@ int smhip_keys_decode(smhip_ctx *ctx, const int64_t *d_keys, int width, int heig
 // keys (d_keys) or the aggregated DSI itself (d_dsi, reference layout, no PadCosts yet).
 static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,
                       const smhip_match_params *p, int window, int d_first, int d_count,
-                      int64_t *d_keys, float *d_dsi, size_t dsi_row_elems)
+                      int64_t *d_keys, float *d_dsi, size_t dsi_row_elems, bool merge = false)
 {
     const int keep_all = d_dsi != nullptr;
     int rc = check_ctx(ctx);
@@ -1467,12 +1467,17 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
     rc = ws_get(ctx, WS_TMP, t_elems * sizeof(float), &T);
     if (rc) return rc;
     long long *kout = (long long *)d_keys;
-    if (n_chunks > 1 && !keep_all) {
+    // merge (smhip_fused_box_wta_keys_merge): the wide pass B of a single chunk takes the minimum with the old key
+    // where it stores; every other shape writes its keys to the workspace and keys_min_kernel folds d_keys in
+    const bool merge_in_b = merge && n_chunks == 1 && wide && !keep_all;
+    const bool merge_after = merge && !merge_in_b && !keep_all;
+    if ((n_chunks > 1 || merge_after) && !keep_all) {
         void *part = nullptr;
         rc = ws_get(ctx, WS_KEYS, n_pix * n_chunks * sizeof(long long), &part);
         if (rc) return rc;
         kout = (long long *)part;
     }
+    const int merge_b = merge_in_b ? 1 : 0;
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
     if (rc) return rc;
@@ -1513,7 +1518,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (!chunked_forced && ctx->opt[SMHIP_OPT_FLOAT_A] != 0) {
             const int max_cost = nbands * (a.sd ? 255 * 255 : 255), pol = ctx->opt[SMHIP_OPT_STORE_POLICY];
             const long a_lds_min = ctx->opt[SMHIP_OPT_A_LDS_KB] < 0 ? -1 : (long)ctx->opt[SMHIP_OPT_A_LDS_KB] * 1024;
-            const int a_one_wave = ctx->opt[SMHIP_OPT_A_NW] == 1;
+            const int a_one_wave = ctx->opt[SMHIP_OPT_A_NW];     // -1: the launcher's policy; 0 / 1 / 4 forced
             if (paired)
                 paired = smk::launch_fused_rawbox_h_f(fa, nbands, (float *)T, tyshift, Dp, window, scale, keep_all, 4,
                                                       a.sd != 0, max_cost, ctx->stream, pol, true, a_lds_min, a_one_wave);
@@ -1601,12 +1606,12 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (kb_lds < b_lds_min) kb_lds = b_lds_min;
 #define LAUNCH_BT(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<WIN, VPL><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
-        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
+        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows, merge_b)
 #define LAUNCH_BT2(WIN, VPL) LAUNCH_BTA(WIN, VPL, 2)
 #define LAUNCH_BT4(WIN, VPL) LAUNCH_BTA(WIN, VPL, (WIN <= 11 ? 4 : 2))
 #define LAUNCH_BTA(WIN, VPL, AH) smk::fused_boxv_wta_vpl_kernel<WIN, VPL, 0, false, false, AH><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
-        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows)
+        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows, merge_b)
         // slabs of up to 128 levels (256- / 512-byte rows per wave): two blocks of rows in flight instead of one,
         // 3-4 % faster from 1280x720 to 3840x2160 (one block of nine such rows per wave is less than the memory's
         // latency x bandwidth); 256-level waves gain nothing from it (0.335 against 0.331 ms).  SMHIP_OPT_B_AHEAD = 1: off
@@ -1632,7 +1637,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             if (plds < b_lds_min) plds = b_lds_min;
 #define LAUNCH_BP(WIN) smk::fused_boxv_wta_vpl_kernel<WIN, 4, 0, false, true><<<gp, 64 * wpb, plds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,                      \
-        d_first, xp, kout, n_pix, nullptr, 0, prow)
+        d_first, xp, kout, n_pix, nullptr, 0, prow, merge_b)
             switch (window) {
             case 3: LAUNCH_BP(3); break;
             case 5: LAUNCH_BP(5); break;
@@ -1690,9 +1695,9 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         }
 #undef LAUNCH_B
     }
-    if (n_chunks > 1 && !keep_all)
+    if ((n_chunks > 1 || merge_after) && !keep_all)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
-            kout, n_chunks, n_pix, (long long *)d_keys);
+            kout, n_chunks, n_pix, (long long *)d_keys, merge ? 1 : 0);
     if (prof) {
         HIP_TRY(hipEventRecord(ev[2], ctx->stream));
         ctx->ev_used++;
@@ -1708,6 +1713,15 @@ int smhip_fused_box_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t
     if (!d_keys)
         return fail(SMHIP_EINVAL, "null key buffer");
     return fused_impl(ctx, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_keys, nullptr, 0);
+}
+
+int smhip_fused_box_wta_keys_merge(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc,
+                                   size_t img_pitch, const smhip_match_params *p, int window,
+                                   int d_first, int d_count, int64_t *d_keys)
+{
+    if (!d_keys)
+        return fail(SMHIP_EINVAL, "null key buffer");
+    return fused_impl(ctx, d_ref, d_mtc, img_pitch, p, window, d_first, d_count, d_keys, nullptr, 0, true);
 }
 
 int smhip_fused_box_dsi(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc, size_t img_pitch,

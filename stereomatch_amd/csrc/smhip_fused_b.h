@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
     long long *__restrict__ keys, size_t keys_chunk_stride, float *__restrict__ S = nullptr,
-    size_t s_row_elems = 0, int kb_rows = 0)          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8 (PAIR: * 16)
+    size_t s_row_elems = 0, int kb_rows = 0,          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8 (PAIR: * 16)
+    int merge = 0)                                     // 1: keys[] holds the keys of other levels; store the minimum
 {
     static_assert(!PAIR || (VPL == 4 && !STORE), "paired columns: four levels per lane, keys out");
     extern __shared__ __attribute__((aligned(16))) long long kbuf_all[];
@@ -234,16 +235,29 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
             }
             const bool col = x < W;                     // (PAIR: kout / kbuf belong to the lane's own column)
             if (kb_rows == 0) {                         // unbuffered (no dynamic LDS given)
-                if (klane < GRP && g0 + klane < H && col)
-                    kout[g0 + klane] = make_key(key_hi, key_lo);
+                if (klane < GRP && g0 + klane < H && col) {
+                    long long v = make_key(key_hi, key_lo);
+                    if (merge) {
+                        const long long o = kout[g0 + klane];
+                        v = o < v ? o : v;
+                    }
+                    kout[g0 + klane] = v;
+                }
                 return;
             }
             if (klane < GRP)
                 kbuf[g0 - kb_first + klane] = make_key(key_hi, key_lo);
             if (g0 + GRP - kb_first == kb_rows || last) {
                 const int n = col ? min(kb_rows, H - kb_first) : 0;
-                for (int i = klane; i < n; i += KLANES)
-                    kout[kb_first + i] = kbuf[i];
+                if (merge) {                            // (the old keys are read in the same long runs the new ones are written in)
+                    for (int i = klane; i < n; i += KLANES) {
+                        const long long o = kout[kb_first + i], v = kbuf[i];
+                        kout[kb_first + i] = o < v ? o : v;
+                    }
+                } else {
+                    for (int i = klane; i < n; i += KLANES)
+                        kout[kb_first + i] = kbuf[i];
+                }
                 kb_first += kb_rows;
             }
         }

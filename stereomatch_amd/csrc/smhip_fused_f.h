@@ -23,10 +23,15 @@
 // Compile with -fno-slp-vectorize (SMHIP build flags): packed f32 instructions cost two plain ones, need
 // register shuffles and cannot take the |.| modifiers.
 //
-// NOTE (gfx950, ROCm 7.2): a buffer_store_dwordx4 with an SGPR soffset whose data registers are rewritten
-// by the next VALU instruction stored the NEW value of its first data register in lanes 12-15 of every
-// 16 (seen on waves sharing a SIMD, early in the launch while the store queue is empty); the compiler
-// inserts no wait state for this form.  dwordx2 / dword stores are not affected -- LPL stays <= 2 here.
+// NOTE (gfx950, ROCm 7.2): a buffer_store_dwordx4 whose data registers are rewritten by the VALU instruction right
+// behind it stores the NEW value in the last lanes of every 16 -- the ">64-bit store data" hazard of the ISA
+// manual.  LLVM's hazard recogniser (GCNHazardRecognizer::createsVALUHazard) exempts MUBUF stores whose soffset is
+// an SGPR, the hardware does not: scripts/experiments/store_hazard.hip places the instructions by hand -- SGPR
+// soffset, rewrite at once: lanes 12-15 of every 16 wrong; one wait state (s_nop 0) between: clean; soffset 0:
+// lanes 8-15 wrong at once, lanes 12-15 still wrong after one wait state (the compiler puts two there itself).
+// So the wait states are missing from the COMPILER's output for the form used here (SGPR step offset); a
+// dwordx4 store in this kernel is followed by an explicit s_nop 1 (put(), LPL == 4).  dwordx2 / dword stores are
+// not affected.  profiles/r03_store_hazard.log, tests/test_gpu_store_hazard.py.
 #pragma once
 
 #include "smhip_fused_defs.h"
@@ -41,6 +46,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // <= FUSED_F_NI * 64 * NW.  Dynamic LDS: nmatch * 8 + nref * 4 bytes.  W * (Dp << tyshift) * 4 < 2^31.
 // glev = levels per lane of the pass B that follows (1, 2 or 4): the granule of the store predicate.
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
+constexpr int fused_f_ni(int lpl) { return lpl == 4 ? 12 : FUSED_F_NI; }   // (a 256-level wave alone stages its row)
 
 template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false, bool W3 = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
 // Waves per SIMD: the kernels of windows up to 9 need 157 VGPRs or fewer, so three waves fit a SIMD; with the
@@ -49,18 +55,18 @@ template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int 
 // take 0.314 ms, 0.80 of 8 TB/s).  Window 11 takes 180 VGPRs: W3 = true forces it under 168 (44-60 bytes of scratch
 // per lane), which costs about 3 % and saves the tail (config 3: 0.379 -> 0.363 ms) -- used when no LDS floor bounds
 // the residency anyway (frames below 1280 rows).
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 1, (WIN <= 9 || W3) ? 3 : 2)))
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(W3 ? 3 : 1, ((WIN <= 9 && LPL <= 2) || W3) ? 3 : 2)))
 void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                                                                    int Dp, float scale, int keep_all, int cb,
                                                                    int nref, int nmatch, int glev)
 {
     static_assert(WIN >= 3 && (WIN & 1), "static odd window");
     static_assert(DS == 1 || DS == -1, "unit disparity step");
-    static_assert(LPL == 1 || LPL == 2, "levels per lane (see the note on dwordx4 buffer stores)");
+    static_assert(LPL == 1 || LPL == 2 || LPL == 4, "levels per lane");
     constexpr int NT = 64 * NW;                        // threads per workgroup
     constexpr int CW = 64 * LPL * NW;                  // levels per workgroup
     constexpr int NPX = WIN + LPL - 1;                 // matching pixels a lane reads per block
-    constexpr int NI = FUSED_F_NI;
+    constexpr int NI = fused_f_ni(LPL);
     constexpr int pr = WIN / 2, pl = pr - WIN;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];
     f32x2 *ml = (f32x2 *)lds_f;                        // matching interval (lo, hi) of positions M0 ..
@@ -215,10 +221,20 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     auto put = [&](int voff, unsigned off, const float (&acc)[LPL]) {
         if constexpr (LPL == 1) {
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[0]), trs, voff, off, POL | (ABL >> 4));
-        } else {
+        } else if constexpr (LPL == 2) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             u32x2 v = {__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1])};
             __builtin_amdgcn_raw_buffer_store_b64(v, trs, voff, off, POL | (ABL >> 4));
+        } else {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 v = {__builtin_bit_cast(unsigned, acc[0]), __builtin_bit_cast(unsigned, acc[1]),
+                       __builtin_bit_cast(unsigned, acc[2]), __builtin_bit_cast(unsigned, acc[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(v, trs, voff, off, POL | (ABL >> 4));
+            // two wait states before anything may rewrite the data registers (see the note at the top): the
+            // compiler's hazard recogniser does not cover a store with an SGPR soffset
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 1");
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     // does one level of the lane's group of glev levels (one lane of pass B, glev a multiple of LPL)

@@ -21,9 +21,17 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
                       hipStream_t stream, bool paired, long lds_min, int one_wave)
 {
     // 256-level chunks: two waves of two levels per lane; a 128-level slab: one wave
-    const int nw = (Dp % 256 == 0 && !one_wave) ? 2 : 1;     // one_wave: experiment / option a_nw
-    const int cw = 128 * nw;
-    int cbs = FUSED_F_NI * 64 * nw - WIN - cw;             // staged pixels per thread bounded by FUSED_F_NI
+    // one_wave (option a_nw): 1 = one-wave workgroups of 128 levels on 256-level chunks too; 4 = one wave of FOUR
+    // levels per lane per 256-level chunk (1-KiB wave stores; window 9 only)
+    const bool lpl4 = one_wave == 4 && WIN == 9 && Dp % 256 == 0 && !paired && glev == 4;
+    // One-wave workgroups on a single 256-level chunk of frames of 1025..1280 rows (config 3: 2160 workgroups, 8.4
+    // per CU, instead of 1080 two-wave ones, 4.2 per CU): pass A 0.352 -> 0.347 ms, windows 3..9; slower on every
+    // other shape measured (512 / 1024 levels 2-5 %, window 11 4 %, 2560x1440 1 %; profiles/r03_pass_a_one_wave.log)
+    if (one_wave < 0)
+        one_wave = (Dp == 256 && WIN <= 9 && a.W < 2560 && a.H > 1024 && a.H <= 1280) ? 1 : 0;
+    const int nw = (Dp % 256 == 0 && !one_wave) ? 2 : 1;
+    const int cw = lpl4 ? 256 : 128 * nw;
+    int cbs = fused_f_ni(lpl4 ? 4 : 2) * 64 * nw - WIN - cw;   // staged pixels per thread bounded by fused_f_ni()
     if (cbs > 480) cbs = 480;
     const int cb = cbs / WIN, nref = cb * WIN + WIN, nmatch = nref + cw;
     // Workgroups resident per CU, bounded through the LDS a workgroup asks for (160 KB per CU).  All rows take
@@ -50,6 +58,13 @@ void launch_shape_pol(const FusedA &a, float *T, int tyshift, int Dp, float scal
     // 2048x1536 3 %, 1280x1400 11 %, 800x1300x512 15 %, 640x4000x128 7 % -- profiles/r02_occupancy.log, last part.)
     if (lds < (size_t)lds_min) lds = (size_t)lds_min;
     dim3 grid((unsigned)a.H * (unsigned)(Dp / cw));        // row-major over (row, chunk)
+    if constexpr (WIN == 9) {
+        if (lpl4) {
+            fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 4, 1, 0, POL><<<grid, 64, lds, stream>>>(a, T, tyshift, Dp, scale,
+                                                                                      keep_all, cb, nref, nmatch, glev);
+            return;
+        }
+    }
     if (nw == 2 && WIN > 9 && a.H < 1280) {                // all rows resident: three waves per SIMD (see the kernel)
         if constexpr (WIN > 9)
             fused_rawbox_h_f_kernel<WIN, SD, CUT, DS, 2, 2, 0, POL, false, true><<<grid, 128, lds, stream>>>(

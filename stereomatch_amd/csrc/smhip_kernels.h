@@ -346,12 +346,16 @@ SMK_GLOBAL void wta_thread_kernel(const float *cost, int W, int H, int D, size_t
     if (best) best[p] = bc;
 }
 
-SMK_GLOBAL void keys_min_kernel(const long long *part, int n_part, size_t n, long long *out)
+SMK_GLOBAL void keys_min_kernel(const long long *part, int n_part, size_t n, long long *out, int merge = 0)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
     long long m = part[i];
+    if (merge) {                        // out[] holds the keys of other levels
+        long long o = out[i];
+        m = o < m ? o : m;
+    }
     for (int c = 1; c < n_part; c++) {
         long long v = part[(size_t)c * n + i];
         m = v < m ? v : m;

@@ -97,6 +97,34 @@ def test_disparity_slabs_merge_to_full_result(gpu_ctx, oracle, D, slabs):
     util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), obest, "merged best cost")
 
 
+@pytest.mark.parametrize("w,h,b,D,win,calls,opts", [
+    (140, 70, 1, 96, 9, 3, {}),                 # 32-level calls: narrow kernels, merged by keys_min_kernel
+    (150, 130, 1, 512, 9, 2, {}),               # 256-level calls: pass B takes the minimum where it stores
+    (150, 130, 1, 512, 5, 2, {"keybuf": 0}),    # ... unbuffered key stores
+    (151, 64, 1, 256, 9, 2, {"paired": 1}),     # 128-level calls, columns in pairs
+    (96, 40, 4, 40, 7, 4, {}),                  # 10-level calls of a 4-band pair
+    (120, 50, 1, 1024, 9, 2, {}),               # 512-level calls: two chunks each + the old keys
+])
+def test_keys_merge_entry_point(gpu_ctx, oracle, w, h, b, D, win, calls, opts):
+    """smhip_fused_box_wta_keys_merge: a level range walked in several calls, each folding its keys into the
+    buffer (min with the key already there), equals the oracle's WTA over the whole range."""
+    left, right, _ = synth.scene_pair(w, h, min(D, 64), n_bands=b)
+    odisp, obest, _, _ = oracle_run(oracle, left, right, disp_max=D - 1, aggr_window_size=win, match_fn=1,
+                                    match_interval=1)
+    p = capi.match_params(w, h, b, D, match_fn=1, match_interval=1)
+    d_ref, d_mtc = gpu_ctx.upload(left), gpu_ctx.upload(right)
+    keys = gpu_ctx.alloc(w * h * 8)
+    bounds = [D * i // calls for i in range(calls + 1)]
+    with gpu_ctx.options(**opts):
+        for i in range(calls):
+            fn = gpu_ctx.fused_box_wta_keys if i == 0 else gpu_ctx.fused_box_wta_keys_merge
+            fn(d_ref, d_mtc, w * b, p, win, bounds[i], bounds[i + 1] - bounds[i], keys)
+    disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
+    gpu_ctx.keys_decode(keys, w, h, disp, best)
+    util.assert_bit_equal(gpu_ctx.download(disp, (h, w), np.int32), odisp, "merged disparity")
+    util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), obest, "merged best cost")
+
+
 @pytest.mark.parametrize("pair,kw", [
     ("scene", dict(match_fn=1, match_interval=1, match_max=1000)),     # BASELINE config 3 as bench.py runs it
     ("noise", dict(match_fn=1, match_interval=1, match_max=1000)),     # SURVEY 8d: the no-structure pair
@@ -119,8 +147,10 @@ def test_config3_full_size_vs_oracle(gpu_ctx, oracle, pair, kw):
         odisp, obest, odepth, _ = oracle_run(O, left, right, disp_max=D - 1, aggr_window_size=9, **kw)
     finally:
         O.use_openmp(False)
-    for float_a, pol in ((1, -1), (1, 0), (1, 18), (0, -1)):   # float-lane pass A (store policies), integer kernels
-        with gpu_ctx.options(float_a=float_a, store_policy=pol):
+    # float-lane pass A (store policies; one-wave workgroups; four levels per lane with 1-KiB dwordx4 stores and
+    # the wait states the compiler leaves out behind them), integer kernels
+    for float_a, pol, a_nw in ((1, -1, -1), (1, 0, -1), (1, 18, -1), (0, -1, -1), (1, -1, 1), (1, -1, 4), (1, 0, 4)):
+        with gpu_ctx.options(float_a=float_a, store_policy=pol, a_nw=a_nw):
             m = matcher.StereoMatcher(ctx=gpu_ctx, disp_max=D - 1, aggr_window_size=9, **kw)
             disp, best, depth = m.ComputeCorrespondence(left, right)
         assert m.used_fused

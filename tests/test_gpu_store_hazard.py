@@ -1,0 +1,33 @@
+"""The ">64-bit store data" hazard behind buffer_store_dwordx4 on gfx950 (smhip_fused_f.h, note at the top):
+scripts/experiments/store_hazard (built here from store_hazard.hip, hand-placed instructions) must show that a
+VALU rewrite of the data registers right behind a dwordx4 buffer store with an SGPR soffset corrupts the store,
+and that the wait state the library puts there (the LPL = 4 pass A: s_nop 1) removes it -- if a later toolchain or
+part changes either, this test says so before a kernel silently depends on it."""
+import os
+import re
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "scripts", "experiments", "store_hazard")
+
+
+def test_dwordx4_store_needs_a_wait_state_the_compiler_omits():
+    if not os.path.exists(BIN):
+        pytest.skip("scripts/experiments/store_hazard not built (hipcc -O3 --offload-arch=gfx950 store_hazard.hip)")
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    wrong = {}
+    for m in re.finditer(r"variant (\d): (\d+) of (\d+) dwords wrong, (\d+) of them hold", r.stdout):
+        wrong.setdefault(int(m.group(1)), []).append((int(m.group(2)), int(m.group(4))))
+    assert set(wrong) == {0, 1, 2, 3, 4, 5}, r.stdout
+    # one wait state behind the SGPR-soffset form, and the compiled loops (an independent instruction or the
+    # compiler's own s_nop in between), are clean
+    for v in (1, 4, 5):
+        assert all(bad == 0 for bad, _ in wrong[v]), (v, wrong[v])
+    # without a wait state the store takes the rewritten value; every wrong dword holds exactly that value
+    for v in (0, 2):
+        assert all(bad > 0 and bad == late for bad, late in wrong[v]), (v, wrong[v])

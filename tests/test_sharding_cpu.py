@@ -83,7 +83,7 @@ def test_gloo_slab_merge_equals_oracle_wta(oracle, tmp_path, world):
     util.assert_bit_equal(b, want_b, "merged best cost")
 
 
-def _pipeline_worker(rank, world, port, cost_path, out_path, n_frames):
+def _pipeline_worker(rank, world, port, cost_path, out_path, n_frames, collective="allreduce"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -92,20 +92,28 @@ def _pipeline_worker(rank, world, port, cost_path, out_path, n_frames):
     d0, n = sharding.slab_bounds(D, world, rank)
     got, log = {}, []
 
+    h, w = cost.shape[1:3]
+
     def produce(buf, f):
         slab = cost[f][:, :, d0:d0 + n]
         local = np.argmin(slab, axis=2)
         best = np.take_along_axis(slab, local[..., None], axis=2)[..., 0]
-        buf.copy_(torch.from_numpy(sharding.encode_keys(best, local + d0).T.copy()))
+        buf.view(-1)[:w * h].copy_(torch.from_numpy(sharding.encode_keys(best, local + d0).T.copy()).view(-1))
         log.append(("p", f))
 
     def consume(buf, f):
-        got[f] = buf.numpy().copy()
+        if collective == "reduce_scatter":          # merged keys on rank 0 only
+            assert (buf is None) == (rank != 0)
+        if buf is not None:
+            got[f] = buf.view(-1)[:w * h].view(w, h).numpy().copy()
         log.append(("c", f))
 
-    h, w = cost.shape[1:3]
-    bufs = [torch.empty((w, h), dtype=torch.int64) for _ in range(2)]
-    pipe = sharding.KeyReducePipeline(bufs, produce, consume)
+    if collective == "reduce_scatter":              # flat buffers padded to a multiple of the ranks
+        n_keys = sharding.padded_key_count(w * h, world)
+        bufs = [torch.full((n_keys,), np.iinfo(np.int64).max, dtype=torch.int64) for _ in range(2)]
+    else:
+        bufs = [torch.empty((w, h), dtype=torch.int64) for _ in range(2)]
+    pipe = sharding.KeyReducePipeline(bufs, produce, consume, collective=collective)
     for f in range(n_frames):
         pipe.submit(f)
     pipe.flush()
@@ -121,10 +129,12 @@ def _pipeline_worker(rank, world, port, cost_path, out_path, n_frames):
     dist.destroy_process_group()
 
 
-def test_gloo_key_reduce_pipeline(oracle, tmp_path):
-    """KeyReducePipeline (double-buffered, all-reduce of frame i under the compute of frame
-    i + 1) returns, for every frame, the oracle's WTA over all levels."""
-    w, h, D, F, world = 40, 12, 16, 5, 2
+@pytest.mark.parametrize("collective,world,w", [("allreduce", 2, 40), ("reduce_scatter", 2, 40), ("reduce_scatter", 3, 41)])
+def test_gloo_key_reduce_pipeline(oracle, tmp_path, collective, world, w):
+    """KeyReducePipeline (double-buffered, the reduction of frame i under the compute of frame
+    i + 1) returns, for every frame, the oracle's WTA over all levels -- as one MIN all-reduce, or as a MIN
+    reduce-scatter whose chunks are gathered on rank 0 (41 x 12 keys over 3 ranks: a padded buffer)."""
+    h, D, F = 12, 16, 5
     costs, want = [], []
     for f in range(F):
         left, right = synth.noise_pair(w, h, 1, seed=synth.SEED_NOISE + f)
@@ -134,7 +144,7 @@ def test_gloo_key_reduce_pipeline(oracle, tmp_path):
         want.append(oracle.wta(c))
     cp, op = str(tmp_path / "costs.npy"), str(tmp_path / "keys.npy")
     np.save(cp, np.stack(costs))
-    mp.spawn(_pipeline_worker, args=(world, _free_port(), cp, op, F), nprocs=world, join=True)
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), cp, op, F, collective), nprocs=world, join=True)
     keys = np.load(op)
     for f in range(F):
         d, b = sharding.decode_keys(keys[f].T)
