@@ -78,6 +78,13 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["BENCH_WATCHDOG"]), exit=True)
 
+    # stdout carries the ONE JSON line and nothing else: libraries that print there (RCCL's version banner at the
+    # first collective) are sent to stderr -- file descriptor 1 is pointed at stderr for the run, the line goes to
+    # a duplicate of the original
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -353,7 +360,7 @@ def main():
             out["cpu_baseline_all_cores"], _ = cpu_baseline(np, left, right, args, Dg, win, openmp=True)
             if "extra" in out:
                 out["extra"]["config4_cpu"] = cpu_config4(np, synth)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
 
     if multi:
         dist.barrier()
