@@ -385,12 +385,12 @@ def extra_configs(np, capi, synth, ctx):
     the fused path on a 7680x4320 slab of 128 levels.  The iterated runs keep several iterations in LDS
     per pass over the DSI (temporal blocking), so "8 bytes per voxel and iteration" is not what they move:
     they are reported with the HBM bytes the PMC counters measured for their kernels at this very shape
-    (profiles/r02_stage_ops_summary.json, scripts/prof_ops_pmc.sh), the rate those bytes give over the time
+    (profiles/r03_stage_ops_summary.json, scripts/prof_ops_pmc.sh), the rate those bytes give over the time
     measured here, and the share of SIMD cycles that had a vector instruction in flight.  Failures are
     reported, they do not stop the bench."""
     res = {}
     ops_prof = {}
-    ops_prof_path = os.path.join(ROOT, "profiles", "r02_stage_ops_summary.json")
+    ops_prof_path = os.path.join(ROOT, "profiles", "r03_stage_ops_summary.json")
     if os.path.exists(ops_prof_path):
         with open(ops_prof_path) as f:
             ops_prof = json.load(f)
@@ -402,6 +402,9 @@ def extra_configs(np, capi, synth, ctx):
         while left > 0:
             k = (left + passes - 1) // passes
             c = ops_prof.get(kernel_fmt % k)
+            if c is None:                       # a depth the profile run did not launch: the nearest one it did
+                near = [ops_prof[kernel_fmt % j] for j in range(1, maxk + 1) if kernel_fmt % j in ops_prof]
+                c = near[-1] if near else None
             if c is None:
                 return {"measured_bytes": None}
             nbytes += c["measured_bytes"]
@@ -410,7 +413,7 @@ def extra_configs(np, capi, synth, ctx):
             left, passes = left - k, passes - 1
         return {"measured_bytes": nbytes, "achieved_GBs": round(nbytes / dt / 1e9, 1),
                 "frac_of_8TBs": round(nbytes / dt / 1e9 / HBM_PEAK_GBS, 3), "valu_active_pct": round(valu_t / t, 1),
-                "counters_source": "profiles/r02_stage_ops_summary.json"}
+                "counters_source": "profiles/r03_stage_ops_summary.json"}
 
     def timed(fn, reps):
         fn()
@@ -429,18 +432,20 @@ def extra_configs(np, capi, synth, ctx):
         d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
         a, b = ctx.alloc(N * 4), ctx.alloc(N * 4)
         ctx.raw_costs(d_ref, d_mtc, W, p, a, W * D)
-        bk, dk = "smk::binomial_multi_kernel<%d>", "smk::diffusion_multi_kernel<%d, false>"
-        for name, iters, kfmt, fn in (
-                ("binomial_x4", 4, bk, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
-                ("binomial_x8", 8, bk, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),
-                ("diffusion_x10", 10, dk, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 10)),
-                ("diffusion_x50", 50, dk, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 50))):
+        # kernels of the _run calls at this shape: the binomial in 128-pixel LDS tiles, up to 4 iterations per pass;
+        # the diffusion in the pixels-on-lanes form, up to 6 per pass (smhip_api.hip)
+        bk, dk = "smk::binomial_multi_kernel<%d, 128>", "smk::iter_px_kernel<1, %d, 32, 0, 0, false, 2>"
+        for name, iters, kfmt, maxk, fn in (
+                ("binomial_x4", 4, bk, 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
+                ("binomial_x8", 8, bk, 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),
+                ("diffusion_x10", 10, dk, 6, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 10)),
+                ("diffusion_x50", 50, dk, 6, lambda: ctx.diffusion_run(a, b, None, W, H, D, W * D, 0.15, 0.0, 50))):
             dt = timed(fn, 2)
             res["config4_" + name] = {
                 "workload": "3840x2160, D=512, %d iterations on the resident DSI" % iters,
                 "ms": round(dt * 1e3, 3), "ms_per_iteration": round(dt * 1e3 / iters, 3),
                 "G_voxel_iterations_per_s": round(N * iters / dt / 1e9, 1)}
-            res["config4_" + name].update(run_counters(kfmt, iters, dt))
+            res["config4_" + name].update(run_counters(kfmt, iters, dt, maxk))
         a.free()
         b.free()
         # one GPU's share of config 4 under slab sharding (D = 512 over 8 GPUs): the staged pipeline on

@@ -32,15 +32,16 @@ def main():
 
     for k, v in opts.items():
         ctx.set_option(k, v)
-    for it in (2, 4, 8):
-        row = []
-        for fused in (1, 0):
-            ctx.set_option("iter_fused", fused)
-            ms = timed(lambda: ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, 2, it, d0, n, keys))
-            row.append(ms)
-        ctx.set_option("iter_fused", -1)
-        print("%dx%d levels [%d,%d) binomial x%d: fused %8.3f ms (%6.1f G px*disp/s)   stage calls %8.3f ms" % (
-            W, H, d0, d0 + n, it, row[0], W * H * n / row[0] / 1e6, row[1]), flush=True)
+    for fn, name, its in ((2, "binomial", (2, 4, 8)), (3, "diffusion", (4, 6, 10, 50))):
+        for it in its:
+            row = []
+            for fused in (1, 0):
+                ctx.set_option("iter_fused", fused)
+                ms = timed(lambda: ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, fn, it, d0, n, keys), 5 if it < 50 else 2)
+                row.append(ms)
+            ctx.set_option("iter_fused", -1)
+            print("%dx%d levels [%d,%d) %s x%d: fused %8.3f ms (%6.1f G px*disp/s)   stage calls %8.3f ms" % (
+                W, H, d0, d0 + n, name, it, row[0], W * H * n / row[0] / 1e6, row[1]), flush=True)
 
 
 if __name__ == "__main__":

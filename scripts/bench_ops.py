@@ -68,6 +68,12 @@ def main():
               lambda: ctx.diffusion_run(cost, cost2, None, W, H, D, re, 0.15, 0.0, n))
     timed("membrane x4 (run)", 12.0 * N,
           lambda: ctx.diffusion_run(cost, cost2, disp_src, W, H, D, re, 0.15, 0.5, 4))
+    keys = ctx.alloc(W * H * 8)
+    half = D // 2 if D >= 64 else D
+    for fn, name, its in ((2, "binomial", (4, 8)), (3, "diffusion", (6, 10))):
+        for it in its:                   # raw costs -> iterations -> PadCosts -> WTA keys, fused (no DSI at <= 4 / 6)
+            timed("fused %s x%d -> keys" % (name, it), 2.0 * W * H + 8.0 * W * H,
+                  lambda: [ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, fn, it, s0, half, keys) for s0 in range(0, D, half)])
     timed("pad_costs", 4.0 * D * D / 2 * H, lambda: ctx.pad_costs(cost, re, p))
     timed("wta", 4.0 * N + 8.0 * W * H, lambda: ctx.wta(cost, W, H, D, re, disp, best))
     if quick:

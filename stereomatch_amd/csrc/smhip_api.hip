@@ -824,6 +824,8 @@ static int multi_maxk(const smhip_ctx *ctx, bool binomial, int nb, size_t volume
     return (nb <= 16 && volume_bytes > ((size_t)32 << 20)) ? 2 : 4;   // tsukuba-size volumes: launches count, depth 4
 }
 
+static int launch_iter_dsi(smhip_ctx *ctx, int op, int K, int src, int nbk, bool sd, smk::IterPxArgs &g);
+
 int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_cost0, int w, int h,
                         int nb, size_t row_elems, float lambda, float beta, int n_iter, int *result_in_b)
 {
@@ -853,6 +855,28 @@ int smhip_diffusion_run(smhip_ctx *ctx, float *d_a, float *d_b, const float *d_c
     }
     float a = 1 - lambda * (beta + 4);   // StcDiffusion.cpp:84
     float lb = lambda * beta;            // :132
+    // Diffusion (beta = 0) on frames whose width is a multiple of 4: the pixels-on-lanes kernel of smhip_iter_px.h,
+    // up to six iterations per pass, horizontal neighbours by DPP instead of LDS (3840x2160x512: 2.2 -> 1.2 ms per
+    // iteration; profiles/r03_iter_fused.log).  SMHIP_OPT_MULTI_PX = 0 keeps the LDS form.
+    if (!mem && w % 4 == 0 && (ctx->opt[SMHIP_OPT_MULTI_PX] > 0 ||
+                               (ctx->opt[SMHIP_OPT_MULTI_PX] < 0 && row_elems * (size_t)h * sizeof(float) >= ((size_t)64 << 20)))) {
+        smk::IterPxArgs g;
+        memset(&g, 0, sizeof(g));
+        g.W = w; g.H = h; g.D = nb; g.row_elems = row_elems;
+        g.lambda = lambda; g.acoef = a;
+        const int pk = smk::iter_px_max_k(smk::IPX_DIFFUSION);
+        int px_passes = (n_iter + pk - 1) / pk;
+        for (int left = n_iter; left > 0; px_passes--) {
+            const int K = multi_depth(left, px_passes);
+            g.src = cur; g.dst = oth;
+            rc = launch_iter_dsi(ctx, smk::IPX_DIFFUSION, K, smk::IPX_DSI, 2, false, g);
+            if (rc) return rc;
+            left -= K;
+            float *t = cur; cur = oth; oth = t;
+            *result_in_b ^= 1;
+        }
+        return SMHIP_OK;
+    }
     const int maxk = multi_maxk(ctx, false, nb, row_elems * (size_t)h * sizeof(float));
     int passes = (n_iter + maxk - 1) / maxk;
     for (int left = n_iter; left > 0; passes--) {
@@ -1824,9 +1848,9 @@ int smhip_pad_wta_keys(smhip_ctx *ctx, float *d_cost, size_t row_elems, const sm
 
 // Rows per workgroup of the keys kernels of smhip_iter_px.h: IPX_SEG at most (the keys of a segment live in LDS),
 // shorter where the frame would give too few workgroups.
-static int iter_keys_seglen(const smhip_ctx *ctx, int w, int h, int K)
+static int iter_keys_seglen(const smhip_ctx *ctx, int w, int h, int op, int K)
 {
-    const int txi = smk::iter_px_tile_pixels(K);
+    const int txi = smk::iter_px_tile_pixels(op, K);
     int seg = smk::IPX_SEG;
     while (seg > 16 && (long)((w + txi - 1) / txi) * ((h + seg - 1) / seg) < 512)
         seg >>= 1;
@@ -1837,11 +1861,11 @@ static int iter_keys_seglen(const smhip_ctx *ctx, int w, int h, int K)
 
 // Launch of a keys-sink kernel of smhip_iter_px.h: the level tiles are dealt to G workgroup groups (blockIdx.y);
 // with G > 1 every group writes a key image of its own and keys_min_kernel merges them.
-static int launch_iter_keys(smhip_ctx *ctx, int K, int src, int nbk, bool sd, smk::IterPxArgs &g, int64_t *d_keys)
+static int launch_iter_keys(smhip_ctx *ctx, int op, int K, int src, int nbk, bool sd, smk::IterPxArgs &g, int64_t *d_keys)
 {
-    const int w = g.W, h = g.H, lv = smk::iter_px_levels(src, smk::IPX_KEYS), txi = smk::iter_px_tile_pixels(K);
+    const int w = g.W, h = g.H, lv = smk::iter_px_levels(src, smk::IPX_KEYS), txi = smk::iter_px_tile_pixels(op, K);
     const int n_tiles = (g.D + lv - 1) / lv;
-    const int seg = iter_keys_seglen(ctx, w, h, K);
+    const int seg = iter_keys_seglen(ctx, w, h, op, K);
     const unsigned gx = (w + txi - 1) / txi, gz = (h + seg - 1) / seg;
     // enough workgroups for a few full rounds of the chip (two 512-thread or one 1024-thread workgroup per CU)
     int G = 1;
@@ -1865,11 +1889,28 @@ static int launch_iter_keys(smhip_ctx *ctx, int K, int src, int nbk, bool sd, sm
     }
     if (gz > 65535)
         return fail(SMHIP_EINVAL, "iterated fused path: more than %d rows", 65535 * seg);
-    if (!smk::launch_iter_px(K, src, smk::IPX_KEYS, nbk, sd, g, gx, (unsigned)G, gz, ctx->stream))
+    if (!smk::launch_iter_px(op, K, src, smk::IPX_KEYS, nbk, sd, g, gx, (unsigned)G, gz, ctx->stream))
         return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K);
     if (G > 1)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
             g.pw.keys, G, n_pix, (long long *)d_keys);
+    HIP_TRY(hipGetLastError());
+    return SMHIP_OK;
+}
+
+// Launch of a DSI-sink kernel of smhip_iter_px.h (source: raw costs or a resident DSI)
+static int launch_iter_dsi(smhip_ctx *ctx, int op, int K, int src, int nbk, bool sd, smk::IterPxArgs &g)
+{
+    const int lv = smk::iter_px_levels(src, smk::IPX_DSI), txi = smk::iter_px_tile_pixels(op, K);
+    int tseg = tile_seglen(ctx, g.W, g.H, g.D);
+    if ((size_t)g.row_elems * g.H * sizeof(float) >= ((size_t)1 << 30) && ctx->opt[SMHIP_OPT_TSEG] < 0 && g.H >= 512)
+        tseg = 256;
+    g.seglen = tseg;
+    const unsigned gz = (g.H + tseg - 1) / tseg, gy = (g.D + lv - 1) / lv;
+    if (gz > 65535 || gy > 65535)
+        return fail(SMHIP_EINVAL, "iterated fused path: grid too large");
+    if (!smk::launch_iter_px(op, K, src, smk::IPX_DSI, nbk, sd, g, (g.W + txi - 1) / txi, gy, gz, ctx->stream))
+        return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K);
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;
 }
@@ -1899,16 +1940,21 @@ int smhip_fused_iter_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_
     const bool ref_point = !(p->match_interval && p->match_interpolated);
     const bool img4 = nb == 4 && img_pitch % 4 == 0 && ((uintptr_t)d_ref & 3) == 0 && ((uintptr_t)d_mtc & 3) == 0;
     const int nbk = (nb == 1 && ref_point) ? 2 : (img4 ? 4 : 0);
-    const bool px_ok = aggr_fn == 2 && n_iter >= 1 && W % 4 == 0 && nbk != 0 && abs(dstep) <= 16 &&
+    // the diffusion model with beta forced to 0 (StcAggregate.cpp:305); the membrane model keeps the stage calls
+    const int op = aggr_fn == 2 ? smk::IPX_BINOMIAL : smk::IPX_DIFFUSION;
+    const bool px_ok = (aggr_fn == 2 || aggr_fn == 3) && n_iter >= 1 && W % 4 == 0 && nbk != 0 && abs(dstep) <= 16 &&
                        ctx->opt[SMHIP_OPT_ITER_FUSED] != 0;
+    const int maxk = smk::iter_px_max_k(op);
     const size_t re = (size_t)W * d_count;                          // row of the private slab DSI
     const size_t vol = re * (size_t)H;
-    const bool two_ends = px_ok && n_iter > 4 && d_count % 4 == 0;
+    const bool several = px_ok && n_iter > maxk && d_count % 4 == 0;
 
     smk::IterPxArgs g;
     memset(&g, 0, sizeof(g));
     g.W = W; g.H = H; g.D = d_count;
     g.force_slow = ctx->opt[SMHIP_OPT_TAP_SLOW] == 1;
+    g.lambda = lambda;
+    g.acoef = 1 - lambda * (0.0f + 4);                              // StcDiffusion.cpp:84 with beta = 0
     g.pw.dstep = dstep;
     g.pw.disp0 = -p->frame_diff_sign * p->disp_min + d_first * dstep;
     g.pw.d_first = d_first;
@@ -1921,15 +1967,12 @@ int smhip_fused_iter_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_
         g.a.bt_inline = 0;
     };
 
-    if (px_ok && n_iter <= 4) {
-        // one kernel, no DSI: every workspace request before the first launch
-        const int lv = smk::iter_px_levels(smk::IPX_RAW, smk::IPX_KEYS);
-        (void)lv;
+    if (px_ok && n_iter <= maxk) {                                  // one kernel, no DSI
         smk::RawArgs a;
         rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
         if (rc) return rc;
         fill_raw(a);
-        return launch_iter_keys(ctx, n_iter, smk::IPX_RAW, nbk, a.sd != 0, g, d_keys);
+        return launch_iter_keys(ctx, op, n_iter, smk::IPX_RAW, nbk, a.sd != 0, g, d_keys);
     }
 
     // a private DSI of the slab (two buffers: the iterated passes ping-pong; membrane keeps the raw costs too)
@@ -1939,36 +1982,47 @@ int smhip_fused_iter_wta_keys(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_
     if (rc) return rc;
     float *A = (float *)ws, *B = A + vol, *C0 = n_buf == 3 ? B + vol : nullptr;
 
-    if (two_ends) {
-        // K1 + (plain passes) + K2 iterations: the first K1 behind the raw costs, the last K2 in front of the WTA
-        int K1 = 4, K2 = 4;
-        if (n_iter < 8) { K1 = (n_iter + 1) / 2; K2 = n_iter - K1; }
-        const int mid = n_iter - K1 - K2;
+    if (several) {
+        // the first iterations behind the raw costs, the last in front of the WTA, plain passes in between
         smk::RawArgs a;
         rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a);
         if (rc) return rc;
         fill_raw(a);
-        const int lv = smk::iter_px_levels(smk::IPX_RAW, smk::IPX_DSI), txi = smk::iter_px_tile_pixels(K1);
-        int tseg = tile_seglen(ctx, W, H, d_count);
-        if (vol * sizeof(float) >= ((size_t)1 << 30) && ctx->opt[SMHIP_OPT_TSEG] < 0 && H >= 512)
-            tseg = 256;
-        g.dst = A; g.row_elems = re; g.seglen = tseg;
-        const unsigned gz = (H + tseg - 1) / tseg;
-        if (gz > 65535 || (d_count + lv - 1) / lv > 65535)
-            return fail(SMHIP_EINVAL, "iterated fused path: grid too large");
-        if (!smk::launch_iter_px(K1, smk::IPX_RAW, smk::IPX_DSI, nbk, a.sd != 0, g, (W + txi - 1) / txi,
-                                 (d_count + lv - 1) / lv, gz, ctx->stream))
-            return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K1);
-        HIP_TRY(hipGetLastError());
-        float *cur = A;
-        if (mid > 0) {
-            int in_b = 0;
-            rc = smhip_convolve_14641_run(ctx, A, B, W, H, d_count, re, mid, &in_b);
+        g.row_elems = re;
+        float *cur = A, *oth = B;
+        int left = n_iter;
+        if (op == smk::IPX_BINOMIAL) {
+            int K1 = 4, K2 = 4;
+            if (n_iter < 8) { K1 = (n_iter + 1) / 2; K2 = n_iter - K1; }
+            g.dst = A;
+            rc = launch_iter_dsi(ctx, op, K1, smk::IPX_RAW, nbk, a.sd != 0, g);
             if (rc) return rc;
-            cur = in_b ? B : A;
+            const int mid = n_iter - K1 - K2;
+            if (mid > 0) {
+                int in_b = 0;
+                rc = smhip_convolve_14641_run(ctx, A, B, W, H, d_count, re, mid, &in_b);
+                if (rc) return rc;
+                cur = in_b ? B : A;
+            }
+            left = K2;
+        } else {
+            // diffusion: passes of nearly equal depth, all in the pixels-on-lanes form (up to six iterations each)
+            int passes = (n_iter + maxk - 1) / maxk;
+            for (int i = 0; passes > 1; passes--, i++) {
+                const int K = multi_depth(left, passes);
+                g.src = cur; g.dst = i == 0 ? cur : oth;
+                if (i == 0) {
+                    rc = launch_iter_dsi(ctx, op, K, smk::IPX_RAW, nbk, a.sd != 0, g);
+                } else {
+                    rc = launch_iter_dsi(ctx, op, K, smk::IPX_DSI, nbk, false, g);
+                    float *t = cur; cur = oth; oth = t;
+                }
+                if (rc) return rc;
+                left -= K;
+            }
         }
         g.src = cur; g.dst = nullptr;
-        return launch_iter_keys(ctx, K2, smk::IPX_DSI, nbk, false, g, d_keys);
+        return launch_iter_keys(ctx, op, left, smk::IPX_DSI, nbk, false, g, d_keys);
     }
 
     // the stage calls on the private DSI: raw costs of the slab, the aggregator, PadCosts + WTA -> keys

@@ -36,6 +36,12 @@ namespace smk {
 constexpr int IPX_SEG = 64;         // rows per segment with the KEYS sink (bounds the key arrays in LDS)
 constexpr int IPX_KSTRIDE = 65;     // keys per pixel in LDS: odd, the pixels a wave updates hit different banks
 enum { IPX_DSI = 0, IPX_RAW = 1, IPX_KEYS = 1 };
+enum { IPX_BINOMIAL = 0, IPX_DIFFUSION = 1 };      // the iterated operator
+// halo of a tile on either side, in pixels (a multiple of the four pixels of a thread) and in rows, per K iterations:
+// the binomial reaches 2 pixels / rows per iteration, the diffusion stencil 1
+constexpr int ipx_halo(int op, int K) { return op == IPX_BINOMIAL ? px_halo(K) : (K + 3) / 4 * 4; }
+constexpr int ipx_txi(int op, int K) { return PX_TXT - 2 * ipx_halo(op, K); }
+constexpr int ipx_rows(int op, int K) { return op == IPX_BINOMIAL ? 2 * K : K; }
 
 struct IterPxArgs {
     const float *src;               // DSI source
@@ -43,6 +49,7 @@ struct IterPxArgs {
     size_t row_elems;
     int W, H, D;                    // width, rows, levels of the volume (slab) handled
     int seglen, force_slow;
+    float lambda, acoef;            // diffusion: out = acoef * c + lambda * (((l + r) + u) + d), acoef = 1 - 4 lambda
     FusedA a;                       // RAW source
     PadWtaArgs pw;                  // KEYS sink
     int tiles_per_group;            // KEYS sink: level tiles a workgroup walks
@@ -111,12 +118,15 @@ template <int QP> __device__ __forceinline__ int segq_allmin_u32(int x)
     }
 }
 
-template <int K, int LV, int SRC, int SINK, bool SD, int NB>
+template <int OP, int K, int LV, int SRC, int SINK, bool SD, int NB>
 __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) void iter_px_kernel(const IterPxArgs g)
 {
     typedef typename fvec<4>::type vec;
     typedef typename PxStage<NB>::word word;
-    constexpr int HL = px_halo(K), TXI = px_txi(K), QP = LV / 4, NT = LV * 32;
+    constexpr int HL = ipx_halo(OP, K), TXI = ipx_txi(OP, K), QP = LV / 4, NT = LV * 32;
+    constexpr int RL = ipx_rows(OP, K);                // rows between a level-0 row and the output row it completes
+    constexpr int PER = OP == IPX_BINOMIAL ? 5 : 3;    // rows per level kept in registers = period of the ring slots
+    constexpr bool BINOM = OP == IPX_BINOMIAL;
     constexpr bool RAW = SRC == IPX_RAW, KEYS = SINK == IPX_KEYS;
     __shared__ __attribute__((aligned(16))) float tin[RAW ? 1 : 2][RAW ? 1 : LV][PX_STRIDE];
     __shared__ __attribute__((aligned(16))) float tout[2][LV][PX_STRIDE];
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
     if (t == 0)
         guard = g.force_slow;
     const vec zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int Rlo = y0 - 2 * K, Rin = y1 - 1 + 2 * K, Rhi = Rin + 1;
+    const int Rlo = y0 - RL, Rin = y1 - 1 + RL, Rhi = Rin + 1;
 
     // ---- per level tile ------------------------------------------------------------------------
     int k0 = 0;                     // first level of the tile
@@ -155,7 +165,8 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
     bool lact = false;              // DSI layout: its four levels exist
     bool padded[4] = {false, false, false, false}, dead[4] = {false, false, false, false};
     int dl = 0, mslot = 0, M0 = 0;  // RAW: this thread's disparity, its first matching slot, first staged matching pixel
-    vec ring[K][5];                 // level j: horizontally filtered rows n-4 .. n, slot = row mod 5
+    vec ring[K][PER];               // binomial: level j's horizontally filtered rows n-4 .. n, slot = row mod 5;
+                                    // diffusion: level j's rows n-2 .. n, slot = row mod 3
     vec nxt = zero, res = zero;
     word pre[2];                    // RAW: the words this thread stages for the next row
     bool slow = false;
@@ -196,7 +207,8 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
     };
     auto step = [&](auto rr, const int R) {
         constexpr int RR = decltype(rr)::value;
-        const int p = (RR & 1) ^ (((R - Rlo) / 5) & 1);     // parity of R - Rlo
+        const int p = PER == 5 ? (RR & 1) ^ (((R - Rlo) / 5) & 1)      // parity of R - Rlo = PER * g + RR
+                               : (RR & 1) ^ (((R - Rlo) / 3) & 1);
         if constexpr (RAW) {
 #pragma unroll
             for (int i = 0; i < 2; i++) {
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
             if (R + 1 <= Rin)
                 fetch_row(R + 1);
         } else {
-            if (!slow && tap_guard_bad(nxt))
+            if (BINOM && !slow && tap_guard_bad(nxt))
                 guard = 1;
 #pragma unroll
             for (int e = 0; e < 4; e++)
@@ -219,9 +231,9 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
         }
         *(vec *)&tout[p][l][4 * q4] = res;      // the row finished at the step before
         __syncthreads();
-        if (!RAW && !slow)                      // the guard of this row's inputs was set before the barrier
+        if (BINOM && !RAW && !slow)             // the guard of this row's inputs was set before the barrier
             slow = __builtin_amdgcn_readfirstlane(guard) != 0;
-        const int qs = R - 1 - 2 * K;           // row in tout
+        const int qs = R - 1 - RL;              // row in tout
         if (qs >= y0 && qs < y1) {
             if constexpr (KEYS) {
                 // PadCosts, then the lowest cost of the pixel's LV levels and the lowest level holding it
@@ -270,6 +282,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
         } else {
             val = *(const vec *)&tin[p][l][4 * q4];
         }
+        if constexpr (BINOM) {
         if ((RAW || !slow) && R - 2 * (K - 1) >= 1 && R <= H - 1) {
             // every level's row lies inside the image and the exact-product taps apply: one basic block
 #pragma unroll
@@ -295,7 +308,38 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                           ring[j][s]);          // level j+1, row n-2
             }
         }
-        res = val;                              // output row R - 2 K
+        } else {
+            // AggrDiffusion (StcDiffusion.cpp:75-120): o = a c + lambda (((l + r) + u) + d), a missing neighbour
+            // replaced by c in its slot.  Level j holds its rows n-2, n-1, n (n = R - j arrives now) and emits
+            // row n-1 of level j+1; rows outside the image are never looked at (u / d fall back to c).
+            const vec la = g.lambda, ac = g.acoef;
+            auto dlevels = [&](auto interior) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const int n = R - j;
+                    const int s = (RR + 3 * K - j) % 3;         // slot of row n; n-1 in s+2, n-2 in s+1 (mod 3)
+                    ring[j][s] = val;
+                    const vec c = ring[j][(s + 2) % 3];
+                    float lf = lane_from_below(c[3], c[0]), rt = lane_from_above(c[0], c[3]);
+                    if (left_edge)
+                        lf = c[0];
+                    if (right_edge)
+                        rt = c[3];
+                    const vec lv = {lf, c[0], c[1], c[2]}, rv = {c[1], c[2], c[3], rt};
+                    vec u = ring[j][(s + 1) % 3], d = val;
+                    if constexpr (!decltype(interior)::value) {
+                        u = (n - 1 > 0) ? u : c;
+                        d = (n - 1 < H - 1) ? d : c;
+                    }
+                    val = ac * c + la * (((lv + rv) + u) + d);  // level j+1, row n-1
+                }
+            };
+            if (R - K > 0 && R <= H - 1)        // every level's centre row has both vertical neighbours
+                dlevels(icst<1>{});
+            else
+                dlevels(icst<0>{});
+        }
+        res = val;                              // output row R - RL
     };
 
     const int n_tiles = KEYS ? g.tiles_per_group : 1;
@@ -321,7 +365,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
         for (int j = 0; j < K; j++)
 #pragma unroll
-            for (int i = 0; i < 5; i++)
+            for (int i = 0; i < PER; i++)
                 ring[j][i] = zero;
         nxt = zero;
         res = zero;
@@ -332,12 +376,14 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 nxt = vload<4>(g.src + (size_t)Rlo * g.row_elems + lcol);
         }
         __syncthreads();            // the buffers of the level tile before are free (and kcost / guard are set)
-        for (int Rb = Rlo; Rb <= Rhi; Rb += 5) {
+        for (int Rb = Rlo; Rb <= Rhi; Rb += PER) {
             step(icst<0>{}, Rb);
             if (Rb + 1 <= Rhi) step(icst<1>{}, Rb + 1);
             if (Rb + 2 <= Rhi) step(icst<2>{}, Rb + 2);
-            if (Rb + 3 <= Rhi) step(icst<3>{}, Rb + 3);
-            if (Rb + 4 <= Rhi) step(icst<4>{}, Rb + 4);
+            if constexpr (PER == 5) {
+                if (Rb + 3 <= Rhi) step(icst<3>{}, Rb + 3);
+                if (Rb + 4 <= Rhi) step(icst<4>{}, Rb + 4);
+            }
         }
     }
     if constexpr (KEYS) {

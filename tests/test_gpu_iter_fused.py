@@ -74,17 +74,42 @@ def test_binomial_two_ends(gpu_ctx, oracle, w, h, b, D, kw, n_iter):
     check(gpu_ctx, oracle, w, h, b, D, 2, n_iter, **kw)
 
 
+@pytest.mark.parametrize("n_iter", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("w,h,b,D,kw", [
+    (128, 40, 1, 16, dict(match_fn=1, match_interval=1)),
+    (252, 70, 1, 40, dict(match_fn=1, match_interval=1, match_max=20, diff_lambda=0.2)),
+    (120, 33, 1, 37, dict(match_fn=2, match_max=50)),
+    (96, 40, 4, 16, dict(match_fn=2)),
+    (8, 3, 1, 4, dict(match_fn=1)),
+    (364, 150, 1, 64, dict(match_fn=1, match_interval=1, diff_lambda=0.05)),
+])
+def test_diffusion_one_kernel(gpu_ctx, oracle, w, h, b, D, kw, n_iter):
+    check(gpu_ctx, oracle, w, h, b, D, 3, n_iter, **kw)
+
+
+@pytest.mark.parametrize("n_iter", [7, 10, 12, 13, 25, 50])
+@pytest.mark.parametrize("w,h,b,D,kw", [
+    (252, 70, 1, 40, dict(match_fn=1, match_interval=1)),
+    (96, 40, 4, 16, dict(match_fn=2, diff_lambda=0.1)),
+    (128, 150, 1, 64, dict(match_fn=1, match_max=7)),
+])
+def test_diffusion_several_passes(gpu_ctx, oracle, w, h, b, D, kw, n_iter):
+    check(gpu_ctx, oracle, w, h, b, D, 3, n_iter, **kw)
+
+
 @pytest.mark.parametrize("n_iter", [2, 4, 6])
 @pytest.mark.parametrize("dmin,step,sign", [(3, 1, 1), (0, 1, -1), (2, 2, 1), (-5, 3, -1), (0, 16, 1)])
 def test_directions_and_steps(gpu_ctx, oracle, dmin, step, sign, n_iter):
-    check(gpu_ctx, oracle, 200, 36, 1, 24, 2, n_iter, dmin=dmin, step=step, sign=sign, match_fn=1, match_interval=1)
-    check(gpu_ctx, oracle, 100, 20, 4, 12, 2, n_iter, dmin=dmin, step=step, sign=sign, match_fn=1)
+    for fn in (2, 3):
+        check(gpu_ctx, oracle, 200, 36, 1, 24, fn, n_iter, dmin=dmin, step=step, sign=sign, match_fn=1, match_interval=1)
+        check(gpu_ctx, oracle, 100, 20, 4, 12, fn, n_iter, dmin=dmin, step=step, sign=sign, match_fn=1)
 
 
 @pytest.mark.parametrize("slabs", [2, 3, 5])
 @pytest.mark.parametrize("n_iter", [3, 4, 8])
 def test_slabs_merge_to_the_whole_range(gpu_ctx, oracle, slabs, n_iter):
     check(gpu_ctx, oracle, 236, 50, 1, 72, 2, n_iter, slabs=slabs, match_fn=1, match_interval=1, match_max=30)
+    check(gpu_ctx, oracle, 236, 50, 1, 72, 3, n_iter + 2, slabs=slabs, match_fn=1, match_interval=1, match_max=30)
 
 
 @pytest.mark.parametrize("opts", [{"iter_groups": 1}, {"iter_groups": 3}, {"iter_groups": 16}, {"tseg": 16}, {"tseg": 8},
@@ -94,6 +119,7 @@ def test_launch_shapes(gpu_ctx, oracle, opts, n_iter):
     with gpu_ctx.options(**opts):
         check(gpu_ctx, oracle, 248, 90, 1, 80, 2, n_iter, match_fn=1, match_interval=1)
         check(gpu_ctx, oracle, 124, 70, 4, 20, 2, n_iter, match_fn=2, match_max=12)
+        check(gpu_ctx, oracle, 248, 90, 1, 80, 3, n_iter + 3, match_fn=1, match_interval=1)
 
 
 @pytest.mark.parametrize("n_iter", [1, 4, 8])
@@ -101,13 +127,14 @@ def test_tie_stress_on_noise(gpu_ctx, oracle, n_iter):
     """Truncated costs on a pair without structure: many exact ties, the lowest level must win."""
     check(gpu_ctx, oracle, 256, 60, 1, 48, 2, n_iter, noise=True, match_fn=1, match_max=2)
     check(gpu_ctx, oracle, 256, 60, 1, 48, 2, n_iter, noise=True, match_fn=1, match_max=1, match_interval=1)
+    check(gpu_ctx, oracle, 256, 60, 1, 48, 3, n_iter + 1, noise=True, match_fn=1, match_max=2)
 
 
 @pytest.mark.parametrize("w,h,b,D,aggr_fn,n_iter,kw", [
     (130, 40, 1, 16, 2, 4, dict(match_fn=1)),                                # width % 4 != 0: stage calls
     (128, 40, 1, 16, 2, 0, dict(match_fn=1, match_interval=1)),              # no iteration at all
-    (128, 40, 1, 16, 3, 5, dict(match_fn=1, match_interval=1)),              # diffusion
-    (96, 30, 4, 12, 3, 10, dict(match_fn=2, diff_lambda=0.2)),
+    (130, 40, 1, 16, 3, 5, dict(match_fn=1, match_interval=1)),              # diffusion, width % 4 != 0
+    (96, 30, 4, 14, 3, 10, dict(match_fn=2, diff_lambda=0.2)),               # ... several passes, levels % 4 != 0
     (128, 40, 1, 16, 4, 3, dict(match_fn=1, diff_beta=0.5)),                 # membrane
     (100, 30, 1, 20, 4, 7, dict(match_fn=1, match_interval=1, diff_lambda=0.1, diff_beta=0.25)),
     (128, 40, 1, 16, 2, 3, dict(match_fn=1, match_interval=1, match_interpolated=1)),   # reference intervals

@@ -402,6 +402,22 @@ def test_binomial_tap_guard(gpu_ctx, oracle, kind, opts, request):
                               "binomial x%d on %s inputs" % (n_iter, kind))
 
 
+@pytest.mark.parametrize("h,w,d", [(40, 128, 8), (150, 252, 40), (70, 364, 12), (3, 8, 4)])
+@pytest.mark.parametrize("n_iter", [1, 3, 6, 7, 10, 20])
+def test_diffusion_run_pixels_on_lanes(gpu_ctx, oracle, h, w, d, n_iter):
+    """smhip_diffusion_run with the pixels-on-lanes passes (up to six iterations each, horizontal neighbours by
+    DPP; the library's choice from 64 MiB on, forced here) == n_iter single iterations of the oracle."""
+    c = util.rand_dsi(h, w, d, 60 + n_iter, "float")
+    want = c
+    for _ in range(n_iter):
+        want = oracle.diffusion_iter(want, 0.15, 0.0, None)
+    with gpu_ctx.options(multi_px=32):
+        bufs = (up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4))
+        in_b = gpu_ctx.diffusion_run(bufs[0], bufs[1], None, w, h, d, w * d, 0.15, 0.0, n_iter)
+    util.assert_bit_equal(gpu_ctx.download(bufs[1] if in_b else bufs[0], (h, w, d), np.float32), want,
+                          "diffusion x%d" % n_iter)
+
+
 def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, request):
     """Large volumes use 128-row segments in the LDS-tiled kernels; force that length on a small
     volume (the `tseg` option) so the segment logic of the production configuration is covered."""
