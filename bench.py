@@ -469,12 +469,14 @@ def extra_configs(np, capi, synth, ctx):
                         "VALU-bound)",
             "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(W * H * n / dt / 1e9, 1),
             "ms_stage_calls": round(dt_staged * 1e3, 3)}
-        for iters in (4, 8):
-            dt = timed(lambda: [ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, 2, iters, s0, 256, keys) for s0 in (0, 256)], 2)
-            res["config4_fused_binomial_x%d" % iters] = {
-                "workload": "3840x2160, D=512 in two calls of 256 levels: raw costs + %d binomial iterations + "
-                            "PadCosts + WTA -> keys, fused" % iters,
-                "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(N / dt / 1e9, 1)}
+        for fn, name, its in ((2, "binomial", (4, 8)), (3, "diffusion", (10, 50))):
+            for iters in its:
+                dt = timed(lambda: [ctx.fused_iter_wta_keys(d_ref, d_mtc, W, p, fn, iters, s0, 256, keys)
+                                    for s0 in (0, 256)], 2)
+                res["config4_fused_%s_x%d" % (name, iters)] = {
+                    "workload": "3840x2160, D=512 in two calls of 256 levels: raw costs + %d %s iterations + "
+                                "PadCosts + WTA -> keys, fused (smhip_fused_iter_wta_keys)" % (iters, name),
+                    "ms": round(dt * 1e3, 3), "G_pixel_disparity_per_s": round(N / dt / 1e9, 1)}
         keys.free()
     except Exception as e:      # noqa: BLE001 - reported, the headline line must still print
         res["config4_error"] = repr(e)

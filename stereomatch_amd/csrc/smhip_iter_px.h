@@ -176,13 +176,15 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
             return vtap5<4>(s0, s1, s2, s3, s4);
         return vtap5_pow2<4>(s0, s1, s2, s3, s4);
     };
-    auto htap = [&](vec v, auto fast) -> vec {
+    auto htap = [&](vec v, auto fast, auto edge) -> vec {
         float l2 = lane_from_below(v[2], v[0]), l3 = lane_from_below(v[3], v[0]);
         float r0 = lane_from_above(v[0], v[3]), r1 = lane_from_above(v[1], v[3]);
-        if (left_edge)
-            l2 = l3 = v[0];
-        if (right_edge)
-            r0 = r1 = v[3];
+        if constexpr (decltype(edge)::value) {   // (only tiles that hold pixel 0 or W-1 pay for the selects)
+            if (left_edge)
+                l2 = l3 = v[0];
+            if (right_edge)
+                r0 = r1 = v[3];
+        }
         const float w[8] = {l2, l3, v[0], v[1], v[2], v[3], r0, r1};
         vec h;
 #pragma unroll
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 pre[i] = PxStage<NB>::fetch_m(g.a, ro, clampi(M0 + it - PX_TXT, W));
         }
     };
-    auto step = [&](auto rr, const int R) {
+    auto step = [&](auto rr, auto edge, const int R) {
         constexpr int RR = decltype(rr)::value;
         const int p = PER == 5 ? (RR & 1) ^ (((R - Rlo) / 5) & 1)      // parity of R - Rlo = PER * g + RR
                                : (RR & 1) ^ (((R - Rlo) / 3) & 1);
@@ -288,7 +290,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const int s = (RR + 10 * K - 2 * j) % 5;
-                ring[j][s] = htap(val, icst<1>{});
+                ring[j][s] = htap(val, icst<1>{}, edge);
                 val = vtap5_pow2<4>(ring[j][(s + 1) % 5], ring[j][(s + 2) % 5], ring[j][(s + 3) % 5],
                                     ring[j][(s + 4) % 5], ring[j][s]);
             }
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 const int n = R - 2 * j;        // row of level j arriving now
                 const int s = (RR + 10 * K - 2 * j) % 5;    // its ring slot; rows n-4 .. n-1 sit in s+1 .. s+4 (mod 5)
                 if (n <= H - 1) {               // rows below the image replicate the last row
-                    ring[j][s] = htap(val, icst<0>{});
+                    ring[j][s] = htap(val, icst<0>{}, edge);
                     if (n == 0)                 // rows above the image replicate row 0
                         ring[j][(s + 3) % 5] = ring[j][(s + 4) % 5] = ring[j][s];
                 } else {
@@ -321,10 +323,12 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                     ring[j][s] = val;
                     const vec c = ring[j][(s + 2) % 3];
                     float lf = lane_from_below(c[3], c[0]), rt = lane_from_above(c[0], c[3]);
-                    if (left_edge)
-                        lf = c[0];
-                    if (right_edge)
-                        rt = c[3];
+                    if constexpr (decltype(edge)::value) {
+                        if (left_edge)
+                            lf = c[0];
+                        if (right_edge)
+                            rt = c[3];
+                    }
                     const vec lv = {lf, c[0], c[1], c[2]}, rv = {c[1], c[2], c[3], rt};
                     vec u = ring[j][(s + 1) % 3], d = val;
                     if constexpr (!decltype(interior)::value) {
@@ -376,15 +380,21 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 nxt = vload<4>(g.src + (size_t)Rlo * g.row_elems + lcol);
         }
         __syncthreads();            // the buffers of the level tile before are free (and kcost / guard are set)
-        for (int Rb = Rlo; Rb <= Rhi; Rb += PER) {
-            step(icst<0>{}, Rb);
-            if (Rb + 1 <= Rhi) step(icst<1>{}, Rb + 1);
-            if (Rb + 2 <= Rhi) step(icst<2>{}, Rb + 2);
-            if constexpr (PER == 5) {
-                if (Rb + 3 <= Rhi) step(icst<3>{}, Rb + 3);
-                if (Rb + 4 <= Rhi) step(icst<4>{}, Rb + 4);
+        auto rows = [&](auto edge) {
+            for (int Rb = Rlo; Rb <= Rhi; Rb += PER) {
+                step(icst<0>{}, edge, Rb);
+                if (Rb + 1 <= Rhi) step(icst<1>{}, edge, Rb + 1);
+                if (Rb + 2 <= Rhi) step(icst<2>{}, edge, Rb + 2);
+                if constexpr (PER == 5) {
+                    if (Rb + 3 <= Rhi) step(icst<3>{}, edge, Rb + 3);
+                    if (Rb + 4 <= Rhi) step(icst<4>{}, edge, Rb + 4);
+                }
             }
-        }
+        };
+        if (X0 <= 0 || X0 + PX_TXT >= W)    // the tile holds an end of the image row (wave-uniform)
+            rows(icst<1>{});
+        else
+            rows(icst<0>{});
     }
     if constexpr (KEYS) {
         __syncthreads();
