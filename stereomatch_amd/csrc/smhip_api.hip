@@ -1787,19 +1787,47 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     pw.d_first = d_first;
     pw.outside = smhip_match_outside(p);
     pw.keys = (long long *)d_keys;
-    // Rows per workgroup: 64 at most (the keys of a segment live in LDS); shorter segments where the frame
-    // would otherwise give too few workgroups (1920x1080: 32 rows, 0.66 ms at 256 levels against 0.76 ms
-    // with 64 and 0.71 ms with 16 -- each segment re-reads WIN - 1 rows).  SMHIP_OPT_TSEG forces a length.
-    const int txo = 64 - (min_window - 1);
+    if (d_count > 65535)
+        return fail(SMHIP_EINVAL, "min filter + WTA keys: more than 65535 levels in one call");
+    // Tile and grid: 64-row segments (the keys of a segment live in LDS) of 64 staged columns; the level tiles are
+    // dealt to G groups of workgroups so that a few rounds of the chip are filled (each group writes a key image,
+    // keys_min_kernel merges them).  Round 2 had to shorten the segments of a 1080-row frame to 32 rows to get enough
+    // workgroups (1.46x the volume read); with the groups 64 rows stay (1.29x): 1920x1080x256 0.66 -> 0.61 ms.
+    // 128 staged columns (1024 threads, one workgroup per CU, 1.20x) read less and take longer: 0.68 ms -- the kernel
+    // is bound by its barriers and LDS reads, not by the bytes (profiles/r03_exp2.log).  SMHIP_OPT_TSEG forces a segment
+    // length, SMHIP_OPT_ITER_GROUPS the number of groups, SMHIP_OPT_MULTI_TXT = 128 the wide tile.
+    const int txs = ctx->opt[SMHIP_OPT_MULTI_TXT] == 128 ? 128 : 64;
+    const int txo = txs - (min_window - 1);
     int seg = smk::MW_SEG;
-    while (seg > 16 && (long)((w + txo - 1) / txo) * ((h + seg - 1) / seg) < 1024)
-        seg >>= 1;
     if (ctx->opt[SMHIP_OPT_TSEG] >= 8 && ctx->opt[SMHIP_OPT_TSEG] <= smk::MW_SEG)
         seg = ctx->opt[SMHIP_OPT_TSEG];
-    dim3 grid((w + txo - 1) / txo, (h + seg - 1) / seg);
+    const int n_tiles = (d_count + 31) / 32;
+    const long wgs = (long)((w + txo - 1) / txo) * ((h + seg - 1) / seg);
+    int G = 1;
+    while (G < n_tiles && G < 16 && wgs * G < (txs == 128 ? 1024 : 2048))
+        G++;
+    if (ctx->opt[SMHIP_OPT_ITER_GROUPS] >= 1)
+        G = ctx->opt[SMHIP_OPT_ITER_GROUPS] < n_tiles ? ctx->opt[SMHIP_OPT_ITER_GROUPS] : n_tiles;
+    if (G > 16) G = 16;
+    const int tpg = (n_tiles + G - 1) / G;
+    G = (n_tiles + tpg - 1) / tpg;
+    const size_t n_pix = (size_t)w * h;
+    if (G > 1) {
+        void *part = nullptr;
+        rc = ws_get(ctx, WS_KEYS, n_pix * G * sizeof(long long), &part);
+        if (rc) return rc;
+        pw.keys = (long long *)part;
+    }
+    dim3 grid((w + txo - 1) / txo, (h + seg - 1) / seg, G);
     if (grid.y > 65535)
         return fail(SMHIP_EINVAL, "min filter + WTA keys: more than %d rows", 65535 * seg);
-#define LAUNCH_MW(WIN) smk::min_wta_tile_kernel<WIN><<<grid, 512, stage_lds(ctx), ctx->stream>>>(d_cost, w, d_count, h, row_elems, seg, pw)
+#define LAUNCH_MW(WIN)                                                                                              \
+    do {                                                                                                            \
+        if (txs == 128) smk::min_wta_tile_kernel<WIN, 128><<<grid, 1024, stage_lds(ctx), ctx->stream>>>(            \
+            d_cost, w, d_count, h, row_elems, seg, pw, tpg, n_pix);                                                 \
+        else smk::min_wta_tile_kernel<WIN, 64><<<grid, 512, stage_lds(ctx), ctx->stream>>>(                         \
+            d_cost, w, d_count, h, row_elems, seg, pw, tpg, n_pix);                                                 \
+    } while (0)
     switch (min_window) {
     case 3: LAUNCH_MW(3); break;
     case 5: LAUNCH_MW(5); break;
@@ -1807,6 +1835,9 @@ int smhip_min_pad_wta_keys(smhip_ctx *ctx, const float *d_cost, size_t row_elems
     case 9: LAUNCH_MW(9); break;
     default: LAUNCH_MW(11); break;
     }
+    if (G > 1)
+        smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(
+            pw.keys, G, n_pix, (long long *)d_keys);
 #undef LAUNCH_MW
     HIP_TRY(hipGetLastError());
     return SMHIP_OK;

@@ -47,24 +47,35 @@ __device__ __forceinline__ int seg8_allmin_u32(int x)
     return x;
 }
 
-template <int WIN>
-__global__ __launch_bounds__(512) void min_wta_tile_kernel(const float *__restrict__ src, int W, int D, int H,
-                                                           size_t row_elems, int seglen, PadWtaArgs pw)
+// TXS = staged pixel columns per tile (64 or 128; threads = 8 TXS).  The level tiles of the slab are dealt to
+// gridDim.z groups (a group walks tiles_per_group of them and writes a key image of its own at
+// keys + blockIdx.z * part_stride; the host merges the groups with keys_min_kernel): long row segments AND enough
+// workgroups, where round 2's kernel had to shorten the segments of a 1080-row frame to 32 rows -- a third of its
+// rows were halo.  The best key of a pixel is kept as ordered cost (int32) + level inside the slab (uint16): a
+// 120-pixel x 64-row segment fits beside the staging buffers.  Tiles come in ascending level order, so a later
+// tile replaces the stored key only with a strictly lower cost (OptWTA's strict '<').
+template <int WIN, int TXS>
+__global__ __launch_bounds__(TXS * 8) void min_wta_tile_kernel(const float *__restrict__ src, int W, int D, int H,
+                                                               size_t row_elems, int seglen, PadWtaArgs pw,
+                                                               int tiles_per_group, size_t part_stride)
 {
     typedef typename fvec<4>::type vec;
     constexpr int PR = WIN / 2, PL = PR - WIN;
-    constexpr int TXO = 64 - (WIN - 1);                 // output pixels per tile
-    __shared__ vec vbuf[2][(64 + WIN - 1) * 8];         // the tail is only read by threads without an output
-    __shared__ long long kbest[TXO * MW_KSTRIDE];       // [pixel][row of the segment]
+    constexpr int TXO = TXS - (WIN - 1);                // output pixels per tile
+    constexpr int NT = TXS * 8;
+    __shared__ vec vbuf[2][(TXS + WIN - 1) * 8];        // the tail is only read by threads without an output
+    __shared__ int kcost[TXO * MW_KSTRIDE];             // [pixel][row of the segment]: best ordered cost ...
+    __shared__ unsigned short klev[TXO * MW_KSTRIDE];   // ... and its level inside the slab
     const int t = threadIdx.x, hp = t >> 3, hl = t & 7;
     const int x0 = blockIdx.x * TXO, y0 = blockIdx.y * seglen, y1 = min(H, y0 + seglen);
-    for (int i = t; i < TXO * MW_KSTRIDE; i += 512)
-        kbest[i] = 0x7FFFFFFFFFFFFFFFll;                // (the row loop's barriers order this before its use)
+    for (int i = t; i < TXO * MW_KSTRIDE; i += NT)
+        kcost[i] = 0x7FFFFFFF;                          // (the row loop's barriers order this before its use)
     const int xs = clampi(x0 + PL + 1 + hp, W);         // staged pixel of this thread (replicate border)
     const bool has_out = hp < TXO && x0 + hp < W;       // output pixel x0 + hp, window = staged hp .. hp + WIN - 1
     const int ylast = y1 - 1 + PR;
     int buf = 0;
-    for (int k0 = 0; k0 < D; k0 += 32) {
+    const int kfirst = (int)blockIdx.z * tiles_per_group * 32, kend = min(D, kfirst + tiles_per_group * 32);
+    for (int k0 = kfirst; k0 < kend; k0 += 32) {
         const bool lact = k0 + hl * 4 < D;
         const float *col = src + (size_t)xs * D + min(k0 + hl * 4, D - 4);
         auto gload = [&](int yy) -> vec { return vload<4>(col + (size_t)clampi(yy, H) * row_elems); };
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(512) void min_wta_tile_kernel(const float *__restri
                         float bc = fmin_hw(fmin_hw(c[0], c[1]), fmin_hw(c[2], c[3]));
                         bc = live ? bc : __builtin_inff();
                         const float mm = seg8_allmin_f32(bc);
-                        const int lev = pw.d_first + k0 + hl * 4;
+                        const int lev = k0 + hl * 4;
                         int cand = 0x7FFFFFFF;
 #pragma unroll
                         for (int e = 3; e >= 0; e--)
@@ -121,10 +132,11 @@ __global__ __launch_bounds__(512) void min_wta_tile_kernel(const float *__restri
                         cand = live ? cand : 0x7FFFFFFF;
                         cand = seg8_allmin_u32(cand);
                         if (hl == 0 && has_out) {
-                            long long *kb = &kbest[hp * MW_KSTRIDE + (yy - PR - y0)];
-                            long long key = make_key(ordered_bits(mm), cand);
-                            if (key < *kb)
-                                *kb = key;
+                            const int idx = hp * MW_KSTRIDE + (yy - PR - y0), oc = ordered_bits(mm);
+                            if (oc < kcost[idx]) {
+                                kcost[idx] = oc;
+                                klev[idx] = (unsigned short)cand;
+                            }
                         }
                         buf ^= 1;
                     }
@@ -138,10 +150,12 @@ __global__ __launch_bounds__(512) void min_wta_tile_kernel(const float *__restri
     }
     __syncthreads();
     const int rows = y1 - y0;
-    for (int i = t; i < TXO * MW_SEG; i += 512) {       // column-major keys: a pixel's rows are contiguous
+    long long *keys = pw.keys + (size_t)blockIdx.z * part_stride;
+    for (int i = t; i < TXO * MW_SEG; i += NT) {        // column-major keys: a pixel's rows are contiguous
         int px = i / MW_SEG, r = i % MW_SEG;
         if (x0 + px < W && r < rows)
-            pw.keys[(size_t)(x0 + px) * H + y0 + r] = kbest[px * MW_KSTRIDE + r];
+            keys[(size_t)(x0 + px) * H + y0 + r] = make_key(kcost[px * MW_KSTRIDE + r],
+                                                            pw.d_first + (int)klev[px * MW_KSTRIDE + r]);
     }
 }
 

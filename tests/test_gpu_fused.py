@@ -253,10 +253,14 @@ def test_min_pad_wta_keys_windows(gpu_ctx, oracle, w, h, D, sign, mf):
     p = capi.match_params(w, h, 1, D, frame_diff_sign=sign)
     d_cost, keys = gpu_ctx.upload(cost), gpu_ctx.alloc(w * h * 8)
     disp, best = gpu_ctx.alloc(w * h * 4), gpu_ctx.alloc(w * h * 4)
-    gpu_ctx.min_pad_wta_keys(d_cost, w * D, p, mf, 0, D, keys)
-    gpu_ctx.keys_decode(keys, w, h, disp, best)
-    assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd)
-    util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "best cost")
+    # the library's tile and grid, then the launch shapes it can be told to take: one group of workgroups for all
+    # level tiles / one per tile (merged by keys_min_kernel), 128 staged columns, short segments
+    for opts in ({}, {"iter_groups": 1}, {"iter_groups": 16}, {"multi_txt": 128}, {"multi_txt": 128, "iter_groups": 2, "tseg": 16}):
+        with gpu_ctx.options(**opts):
+            gpu_ctx.min_pad_wta_keys(d_cost, w * D, p, mf, 0, D, keys)
+        gpu_ctx.keys_decode(keys, w, h, disp, best)
+        assert np.array_equal(gpu_ctx.download(disp, (h, w), np.int32), wd), opts
+        util.assert_bit_equal(gpu_ctx.download(best, (h, w), np.float32), wb, "best cost %r" % (opts,))
 
 
 def test_exp2_pipeline_fused_equals_staged(gpu_ctx, oracle):
