@@ -71,6 +71,8 @@ def main():
                     help="N > 1: how the per-pixel keys of the ranks are merged -- one int64 MIN all-reduce (every "
                          "rank ends with the merged keys and decodes them), or a MIN reduce-scatter whose chunks are "
                          "gathered and decoded on rank 0 only (half the xGMI traffic)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="experiments: a launch-shape option of the library (capi.OPTIONS), e.g. b_lred=0; never a result")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-launch HBM bytes from rocprofv3 --pmc passes (see profiles/README.md)")
     args = ap.parse_args()
@@ -132,6 +134,9 @@ def main():
     left, right, _ = synth.scene_pair(W, H, min(D, 256), n_bands=b)
 
     ctx = capi.Context(local_rank)
+    for nv in args.option:
+        name, value = nv.split("=")
+        ctx.set_option(name, int(value))
     # an explicit stream for the library's kernels and torch's collectives alike: the legacy null
     # stream synchronises implicitly with every blocking stream of the process, which neither the
     # overlap of the all-reduce with the next frame nor torch's helper threads want

@@ -39,5 +39,37 @@ int main()
         RUNK(2, 4, 0, "no key stores");
         RUNK(3, 4, 0, "no reduce, no key stores");
     }
+    // 128-level slabs on a narrow frame (1920 waves of 512-byte rows): what bounds the walk there?
+    {
+        const int Dp2 = 128;
+        double B2 = (double)W * H * Dp2 * 4;
+#define RUN2(ABL, AH, KB, NAME) timeit(NAME, B2, [&] { dim3 g(8 * ((xpx + 3) / 4), 1); \
+    smk::fused_boxv_wta_vpl_kernel<9, 2, ABL, false, false, AH><<<g, 256, (size_t)4 * KB * 8>>>(T, tyshift, W, H, Dp2, Dp2, 9, scale, 0, -1, 1000.f, 0, xpx, keys, (size_t)W * H, nullptr, 0, KB); })
+        for (int rep = 0; rep < 3; rep++) {
+            RUN2(0, 4, 63 * 18, "128 levels: full, ahead 4");
+            RUN2(1, 4, 63 * 18, "128 levels: no wave reduce, ahead 4");
+            RUN2(2, 4, 63 * 18, "128 levels: no key stores, ahead 4");
+            RUN2(3, 4, 63 * 18, "128 levels: no reduce, no key stores");
+            RUN2(0, 2, 63 * 18, "128 levels: full, ahead 2");
+            RUN2(1, 2, 63 * 18, "128 levels: no wave reduce, ahead 2");
+        }
+    }
+    // paired columns (128-level slabs from 3584 columns on; config 5's share per GPU at N = 8 is 7680 x 4320 x 128)
+    {
+        CK(hipFree(T)); CK(hipFree(keys));
+        const int W3 = 7680, H3 = 4320, Dp3 = 128;
+        CK(hipMalloc(&T, (size_t)W3 * Dp3 * (H3 + 32) * 4)); CK(hipMalloc(&keys, (size_t)W3 * H3 * 8));
+        CK(hipMemset(T, 0, (size_t)W3 * Dp3 * (H3 + 32) * 4));
+        double B3 = (double)W3 * H3 * Dp3 * 4;
+        const int xp = ((W3 + 1) / 2 + 7) / 8, prow = 27 * 42;
+#define RUN3(ABL, NAME) timeit(NAME, B3, [&] { dim3 g(8 * ((xp + 3) / 4), 1); \
+    smk::fused_boxv_wta_vpl_kernel<9, 4, ABL, false, true><<<g, 256, (size_t)4 * 2 * prow * 8>>>(T, tyshift, W3, H3, Dp3, Dp3, 9, scale, 0, -1, 1000.f, 0, xp, keys, (size_t)W3 * H3, nullptr, 0, prow); })
+        for (int rep = 0; rep < 2; rep++) {
+            RUN3(0, "8K x 128 paired: full");
+            RUN3(1, "8K x 128 paired: no wave reduce");
+            RUN3(2, "8K x 128 paired: no key stores");
+            RUN3(3, "8K x 128 paired: no reduce, no key stores");
+        }
+    }
     return 0;
 }

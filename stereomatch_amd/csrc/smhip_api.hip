@@ -1616,13 +1616,23 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         // and go to memory in long runs: stores into the read stream cost HBM bus turn-arounds
         const bool b_static = window >= 3 && window <= 17 && (window & 1);
         const int kblk = smk::passb_blk(b_static ? window : 0);
-        const int kgrp = (64 / kblk) * kblk;
+        // slabs of up to 128 levels: four blocks of rows in flight where few waves walk (up to 2048 columns; windows
+        // up to 11): 1920x1080x128 0.252 -> 0.244 (two) -> 0.239 ms (four), x64 0.213 -> 0.196, 1280x720x128 0.170 ->
+        // 0.160; 3072 columns: 0.470 / 0.471 / 0.478 -- and there the minimum over the lanes is taken per group of rows
+        // through LDS instead of per row with DPP (smhip_fused_b.h, LRED); SMHIP_OPT_B_LRED = 1 / 0 forces / forbids it
+        const bool ahead2 = ctx->opt[SMHIP_OPT_B_AHEAD] != 1;
+        const bool few_cols = (long)W * n_chunks <= 2048;
+        const bool ahead4 = ahead2 && few_cols && ctx->opt[SMHIP_OPT_B_AHEAD] != 2;
+        const bool lred = !keep_all && !paired && b_static && window <= 11 && CH <= 128 &&
+                          (ctx->opt[SMHIP_OPT_B_LRED] < 0 ? ahead4 : ctx->opt[SMHIP_OPT_B_LRED] != 0);
+        const int kgrp = ((lred ? 32 : 64) / kblk) * kblk;
         // (two workgroups per CU leave each 80 KB: 36 groups, 8K x 256 5.54 -> 5.42 ms)
         int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (b_policy && b_waves == 8 ? 36 : 18);   // 0: unbuffered
+        if (lred && ctx->opt[SMHIP_OPT_KEYBUF] < 0) kb_groups = (1134 + kgrp - 1) / kgrp;   // (the same ~9-KB runs out of shorter groups)
         if (kb_groups > (H + kgrp - 1) / kgrp) kb_groups = (H + kgrp - 1) / kgrp;
         if (kb_groups > 64) kb_groups = 64;                 // 4 waves x 64 groups x 64 rows x 8 B = 128 KB
         const int kb_rows = kgrp * kb_groups;
-        size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long);
+        size_t kb_lds = (size_t)wpb * kb_rows * sizeof(long long) + (lred ? (size_t)wpb * 32 * 65 * sizeof(int) : 0);
         // 160 KB of LDS per CU, the exact share.  (Asking for 4 KB less -- 76 instead of 80 KB, still two workgroups
         // per CU -- measured 1.44 instead of 1.29 ms at 3840x2160x256: unexplained, so the share stays exact; a third
         // of 160 KB, 53.25 KB, gives two per CU, not three.)
@@ -1633,20 +1643,19 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows, merge_b)
 #define LAUNCH_BT2(WIN, VPL) LAUNCH_BTA(WIN, VPL, 2)
 #define LAUNCH_BT4(WIN, VPL) LAUNCH_BTA(WIN, VPL, (WIN <= 11 ? 4 : 2))
+#define LAUNCH_BTL(WIN, VPL) smk::fused_boxv_wta_vpl_kernel<(WIN >= 3 && WIN <= 11 ? WIN : 9), VPL, 0, false, false, 4, true><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
+        (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
+        d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows, merge_b)
 #define LAUNCH_BTA(WIN, VPL, AH) smk::fused_boxv_wta_vpl_kernel<WIN, VPL, 0, false, false, AH><<<gb, 64 * wpb, kb_lds, ctx->stream>>>( \
         (const float *)T, tyshift, W, H, Dp, d_count, window, scale, a.disp0, a.dstep, outside,        \
         d_first, x_per_xcd, kout, n_pix, nullptr, 0, kb_rows, merge_b)
         // slabs of up to 128 levels (256- / 512-byte rows per wave): two blocks of rows in flight instead of one,
         // 3-4 % faster from 1280x720 to 3840x2160 (one block of nine such rows per wave is less than the memory's
         // latency x bandwidth); 256-level waves gain nothing from it (0.335 against 0.331 ms).  SMHIP_OPT_B_AHEAD = 1: off
-        const bool ahead2 = ctx->opt[SMHIP_OPT_B_AHEAD] != 1;
-        // ... and four blocks where few waves walk (up to 2048 columns; windows up to 11): 1920x1080x128 0.252 -> 0.244
-        // (two) -> 0.239 ms (four), x64 0.213 -> 0.196, 1280x720x128 0.170 -> 0.160; 3072 columns: 0.470 / 0.471 / 0.478
-        const bool ahead4 = ahead2 && (long)W * n_chunks <= 2048 && ctx->opt[SMHIP_OPT_B_AHEAD] != 2;
 #define LAUNCH_BW(WIN)                                 \
         switch (CH / 64) {                             \
-        case 1: if (ahead4 && WIN) LAUNCH_BT4(WIN, 1); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 1); else LAUNCH_BT(WIN, 1); break; \
-        case 2: if (ahead4 && WIN) LAUNCH_BT4(WIN, 2); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 2); else LAUNCH_BT(WIN, 2); break; \
+        case 1: if (lred && WIN) LAUNCH_BTL(WIN, 1); else if (ahead4 && WIN) LAUNCH_BT4(WIN, 1); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 1); else LAUNCH_BT(WIN, 1); break; \
+        case 2: if (lred && WIN) LAUNCH_BTL(WIN, 2); else if (ahead4 && WIN) LAUNCH_BT4(WIN, 2); else if (ahead2 && WIN) LAUNCH_BT2(WIN, 2); else LAUNCH_BT(WIN, 2); break; \
         default: LAUNCH_BT(WIN, 4); break;             \
         }
         if (paired) {                // (the float-lane pass A ran: window 3 .. 11, Dp 128, keys out)
@@ -1701,6 +1710,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         }
 #undef LAUNCH_BW
 #undef LAUNCH_BT4
+#undef LAUNCH_BTL
 #undef LAUNCH_BT2
 #undef LAUNCH_BTA
 #undef LAUNCH_BT

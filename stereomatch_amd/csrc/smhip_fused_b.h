@@ -57,7 +57,16 @@ __device__ __forceinline__ void load_row(const float *p, float (&v)[VPL])
 // unpaired 128-level slab is read with 512-byte loads, whose ceiling is 0.68 instead of 0.86 of 8 TB/s,
 // scripts/membw8.hip), the two columns are independent (no exchange between the half-waves), and one DPP
 // reduction over each half-wave serves two pixels.  W, H stay the image's; Dp must be 128.
-template <int WIN, int VPL, int ABL = 0, bool STORE = false, bool PAIR = false, int AHEAD = 1>   // ABL: ablation switches of scripts/bench_b.hip (0 = product); AHEAD: blocks of rolling prefetch
+// LRED = true (VPL 1 / 2, keys out): the minimum over the 64 lanes is not taken row by row with a DPP chain
+// (seven dependent steps, a ballot, two readlanes: about 300 clocks of latency per row, which nothing hides
+// when a frame gives each SIMD fewer than two waves -- 1920x1080x128: pass B 0.227 ms, without the reduction
+// 0.170, scripts/bench_b.hip) but for a whole group of rows at once: every row's 64 ordered costs go to a
+// wave-private LDS tile red[row][lane] (row stride 65 words), and when the group is complete lane r (and lane
+// r + 32 for the upper half of the levels) scans row r -- 32 conflict-free reads, compare + two selects each, the
+// scan order and the strict '<' keep the lowest level -- and so ends up holding exactly the key it has to store.
+// The level inside the winning lane (VPL 2: one bit per row, collected in a register) comes by ds_bpermute.
+// Groups are (32 / BLK) * BLK rows; dynamic LDS: the key buffers, then 32 x 65 words per wave.
+template <int WIN, int VPL, int ABL = 0, bool STORE = false, bool PAIR = false, int AHEAD = 1, bool LRED = false>   // ABL: ablation switches of scripts/bench_b.hip (0 = product); AHEAD: blocks of rolling prefetch
 __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     const float *__restrict__ T, int tyshift, int W, int H, int Dp, int D, int win, float scale,
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
@@ -66,11 +75,13 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     int merge = 0)                                     // 1: keys[] holds the keys of other levels; store the minimum
 {
     static_assert(!PAIR || (VPL == 4 && !STORE), "paired columns: four levels per lane, keys out");
+    static_assert(!LRED || (VPL <= 2 && !STORE && !PAIR), "row groups reduced through LDS: one or two levels per lane, keys out");
     extern __shared__ __attribute__((aligned(16))) long long kbuf_all[];
     constexpr int BLK = passb_blk(WIN);
     constexpr int OFF = WIN ? BLK - WIN : 0;           // the block before: its last WIN rows are still needed
     constexpr int KLANES = PAIR ? 32 : 64;             // lanes that keep the keys of one pixel column
-    constexpr int GRP = (KLANES / BLK) * BLK;          // rows per key store (63 for WIN 9; PAIR: 27)
+    constexpr int GRP = ((LRED ? 32 : KLANES) / BLK) * BLK;   // rows per key store (63 for WIN 9; PAIR, LRED: 27)
+    constexpr int RSTRIDE = 65;                        // LRED: words per row of the reduction tile
     constexpr int CH = 64 * VPL;
     const int lane = threadIdx.x & 63;
     const int klane = PAIR ? (lane & 31) : lane;
@@ -93,6 +104,8 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     long long *kout = keys + (size_t)chunk * keys_chunk_stride + (size_t)min(x, W - 1) * H;
     long long *kbuf = kbuf_all + (size_t)wib * kb_rows * (PAIR ? 2 : 1) + (PAIR ? (size_t)(lane >> 5) * kb_rows : 0);
     int kb_first = 0;                                  // first row held in the LDS key buffer
+    int *red = LRED ? (int *)(kbuf_all + (size_t)wpb * kb_rows) + wib * (32 * RSTRIDE) : nullptr;
+    unsigned bip = 0;                                  // LRED, VPL 2: bit `slot` = which of the lane's two levels won row `slot`
 
     bool padded[VPL], live[VPL], repl[VPL];
     float replv[VPL];                                  // what PadCosts / the end of the slab put in the level's place
@@ -211,7 +224,11 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
             key_hi += s;
             return;
         }
-        if constexpr (PAIR) {
+        if constexpr (LRED) {
+            red[slot * RSTRIDE + lane] = s;
+            if constexpr (VPL > 1)
+                bip |= (unsigned)bi << slot;
+        } else if constexpr (PAIR) {
             row_key_pair(s, bi, slot);
         } else {
             int m = wave_min_i32(s);
@@ -228,6 +245,36 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
         int g0 = (yb / GRP) * GRP;                      // first row of the group
         bool last = yb + BLK >= H;
         if (yb + BLK - g0 == GRP || last) {
+            if constexpr (LRED) {                       // the group's rows: lane r takes row r, the halves of the wave 32 levels (lanes) each
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int r = lane & 31, half = lane & 32;
+                const int *row = red + r * RSTRIDE + half;
+                int m = row[0], wl = 0;
+#pragma unroll
+                for (int i = 1; i < 32; i++) {
+                    const int v = row[i];
+                    const bool lt = v < m;              // strict: the lowest lane (level) keeps a tie
+                    m = lt ? v : m;
+                    wl = lt ? i : wl;
+                }
+                wl += half;
+                const int m1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, m);
+                const int w1 = __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, wl);
+                if (m1 < m) {                           // (lanes 0 .. 31: the upper half wins only when smaller; lanes 32 .. 63 hold no key)
+                    m = m1;
+                    wl = w1;
+                }
+                int bi = 0;
+                if constexpr (VPL > 1)
+                    bi = ((unsigned)__builtin_amdgcn_ds_bpermute(wl << 2, (int)bip) >> r) & 1;
+                key_lo = d_first + chunk * CH + wl * VPL + bi;
+                key_hi = m;
+                bip = 0;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
             if (ABL & 2) {                              // ablation: (almost) no key stores
                 if (last && lane == 0)
                     kout[0] = make_key(key_hi, key_lo);

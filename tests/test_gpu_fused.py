@@ -312,14 +312,17 @@ def test_slabs_of_65_to_128_levels(gpu_ctx, oracle, w, h, b, D, win, sign):
     kw = dict(disp_max=D - 1, frame_ref=fr, frame_match=fm, match_fn=1, match_max=4, match_interval=1,
               aggr_window_size=win)
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-    for paired in (1, 0):            # columns in pairs (one band, windows 3..11; forced: the library pairs from 3584 columns on) / one column per wave
+    # columns in pairs (one band, windows 3..11; forced: the library pairs from 3584 columns on) / one column per
+    # wave with the minimum over the lanes per group of rows through LDS (the library's choice up to 2048 columns)
+    # / ... per row with the DPP chain
+    for paired, lred in ((1, -1), (0, -1), (0, 0)):
         for keybuf in (-1, 0, 1):
-            with gpu_ctx.options(keybuf=keybuf, paired=paired):
+            with gpu_ctx.options(keybuf=keybuf, paired=paired, b_lred=lred):
                 m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
                 disp, best, _ = m.ComputeCorrespondence(left, right)
             assert m.used_fused
-            assert np.array_equal(disp, odisp), (paired, keybuf)
-            util.assert_bit_equal(best, obest, "best cost (paired %d, keybuf %d)" % (paired, keybuf))
+            assert np.array_equal(disp, odisp), (paired, lred, keybuf)
+            util.assert_bit_equal(best, obest, "best cost (paired %d, lred %d, keybuf %d)" % (paired, lred, keybuf))
 
 
 @pytest.mark.parametrize("win", [3, 5, 9, 13, 15, 17])
@@ -336,13 +339,15 @@ def test_pass_b_blocks_of_other_windows(gpu_ctx, oracle, win, D):
         left, right = synth.noise_pair(w, h, 1, seed=win * 100 + h)
         kw = dict(disp_max=D - 1, match_fn=1, match_max=6, match_interval=1, aggr_window_size=win)
         odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
-        for keybuf, ahead in ((-1, -1), (0, -1), (-1, 1), (-1, 2)):   # (ahead: levels <= 128 keep four / one / two blocks of rows in flight)
-            with gpu_ctx.options(keybuf=keybuf, b_ahead=ahead):
+        # (ahead: levels <= 128 keep four / one / two blocks of rows in flight; lred: their wave minimum per group of
+        # rows through LDS -- the default on frames this narrow, windows up to 11 -- or per row with DPP)
+        for keybuf, ahead, lred in ((-1, -1, -1), (0, -1, -1), (-1, 1, -1), (-1, 2, -1), (-1, -1, 0), (0, 2, 1), (2, 1, 1)):
+            with gpu_ctx.options(keybuf=keybuf, b_ahead=ahead, b_lred=lred):
                 m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
                 disp, best, _ = m.ComputeCorrespondence(left, right)
             assert m.used_fused
-            assert np.array_equal(disp, odisp), (h, keybuf, ahead)
-            util.assert_bit_equal(best, obest, "best cost (h %d, keybuf %d, ahead %d)" % (h, keybuf, ahead))
+            assert np.array_equal(disp, odisp), (h, keybuf, ahead, lred)
+            util.assert_bit_equal(best, obest, "best cost (h %d, keybuf %d, ahead %d, lred %d)" % (h, keybuf, ahead, lred))
 
 
 @pytest.mark.parametrize("w,h,D,win", [(70, 40, 256, 9), (41, 33, 128, 9), (300, 21, 500, 7), (64, 140, 200, 5)])
@@ -354,7 +359,7 @@ def test_occupancy_options(gpu_ctx, oracle, w, h, D, win):
     odisp, obest, _, _ = oracle_run(oracle, left, right, **kw)
     for opts in (dict(a_lds_kb=0, b_waves=0), dict(a_lds_kb=54, b_waves=8), dict(a_lds_kb=26, b_waves=6),
                  dict(a_lds_kb=80, b_waves=16), dict(b_waves=10, keybuf=2), dict(a_lds_kb=41, paired=1),
-                 dict(b_ahead=1), dict(b_ahead=2, paired=0)):
+                 dict(b_ahead=1), dict(b_ahead=2, paired=0), dict(b_lred=0), dict(b_lred=1, b_waves=8)):
         with gpu_ctx.options(**opts):
             m = matcher.StereoMatcher(ctx=gpu_ctx, **kw)
             disp, best, _ = m.ComputeCorrespondence(left, right)

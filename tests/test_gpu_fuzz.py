@@ -128,7 +128,7 @@ def test_random_slab_partition(gpu_ctx, oracle, seed):
         w = max(w, win)
     opts = dict(paired=int(r2.choice([-1, 0, 1])), a_lds_kb=int(r2.choice([-1, 0, 26, 54])),
                 b_waves=int(r2.choice([-1, 0, 6, 8, 12])), keybuf=int(r2.choice([-1, -1, 0, 1, 3])),
-                b_ahead=int(r2.choice([-1, 1, 2])))
+                b_ahead=int(r2.choice([-1, 1, 2])), b_lred=int(r2.choice([-1, -1, 0, 1])))
     seq = dict(disp_min=0, disp_max=D - 1)
     if sign:
         seq.update(frame_ref=1, frame_match=0)
