@@ -38,6 +38,7 @@ int main()
         RUNK(1, 4, 63 * 18, "no wave reduce, 1134 rows");
         RUNK(2, 4, 0, "no key stores");
         RUNK(3, 4, 0, "no reduce, no key stores");
+        RUNK(4, 4, 63 * 18, "non-temporal key stores, 1134 rows");
     }
     // 128-level slabs on a narrow frame (1920 waves of 512-byte rows): what bounds the walk there?
     {
@@ -69,6 +70,7 @@ int main()
             RUN3(1, "8K x 128 paired: no wave reduce");
             RUN3(2, "8K x 128 paired: no key stores");
             RUN3(3, "8K x 128 paired: no reduce, no key stores");
+            RUN3(4, "8K x 128 paired: non-temporal key stores");
         }
     }
     return 0;

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -o pipefail
+mkdir -p gpurun_out
+timeout -k 10 900 python -u -m pytest tests/test_gpu_fused.py -x -q -m gpu --timeout 300 --timeout-method thread > gpurun_out/r3_nt_tests.log 2>&1 || { tail -30 gpurun_out/r3_nt_tests.log; exit 1; }
+tail -3 gpurun_out/r3_nt_tests.log
+run() { timeout -k 10 200 python -u bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra --sustained-seconds 0 "$@" > gpurun_out/b.json 2> gpurun_out/bench.err || { tail -3 gpurun_out/bench.err; exit 1; }
+python -c "
+import json; d=json.load(open('gpurun_out/b.json')); print('$*', d['value'], d['ms_per_step'], [(k['kernel'][:16], k['avg_ms'], k['frac']) for k in d['kernels']], d['roofline_fused']['frac'])"; }
+run --width 5120 --height 2880 --disp-total 128 &&
+run --width 4096 --height 2160 --disp-total 128 &&
+run --width 4608 --height 2592 --disp-total 128 &&
+run --width 6144 --height 3456 --disp-total 128 &&
+run --width 7680 --height 4320 --disp-total 128

@@ -1663,6 +1663,23 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
             dim3 gp(8 * ((xp + wpb - 1) / wpb), 1);
             const int pgrp = (32 / smk::passb_blk(window)) * smk::passb_blk(window);   // rows per key group of a half-wave
             int pg = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (1134 + pgrp - 1) / pgrp;   // runs of ~9 KB per column, as above
+            if (ctx->opt[SMHIP_OPT_KEYBUF] < 0 && b_policy) {
+                // That buffer (72 KB per workgroup) lets two workgroups share a CU, and the grid runs in rounds of 64 per
+                // XCD: when the last round would be less than 0.8 full, a smaller buffer -- three or four workgroups per
+                // CU -- that fills its rounds better (5120x2880x128, 80 workgroups per XCD: 1.54 ms in rounds of 64)
+                const long wg_xcd = (xp + wpb - 1) / wpb;
+                auto fill = [&](long per_cu) {
+                    const long slots = 32 * per_cu;
+                    return (double)wg_xcd / (double)((wg_xcd + slots - 1) / slots * slots);
+                };
+                int per_cu = 2;
+                if (fill(2) < 0.8) {
+                    per_cu = fill(3) >= fill(4) - 0.05 ? 3 : 4;
+                    if (fill(per_cu) <= fill(2)) per_cu = 2;
+                }
+                const int fit = (int)((163840 / per_cu) / ((size_t)wpb * 2 * pgrp * sizeof(long long)));
+                if (per_cu > 2 && pg > fit) pg = fit;
+            }
             if (pg > (H + pgrp - 1) / pgrp) pg = (H + pgrp - 1) / pgrp;
             if (pg > 64) pg = 64;                       // 4 waves x 2 columns x 64 groups x 32 rows x 8 B = 128 KB
             const int prow = pgrp * pg;
