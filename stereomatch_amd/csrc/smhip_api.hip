@@ -1619,16 +1619,39 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         // slabs of up to 128 levels: four blocks of rows in flight where few waves walk (up to 2048 columns; windows
         // up to 11): 1920x1080x128 0.252 -> 0.244 (two) -> 0.239 ms (four), x64 0.213 -> 0.196, 1280x720x128 0.170 ->
         // 0.160; 3072 columns: 0.470 / 0.471 / 0.478 -- and there the minimum over the lanes is taken per group of rows
-        // through LDS instead of per row with DPP (smhip_fused_b.h, LRED); SMHIP_OPT_B_LRED = 1 / 0 forces / forbids it
+        // through LDS instead of per row with DPP (smhip_fused_b.h, LRED); SMHIP_OPT_B_LRED = 1 / 0 forces / forbids it.
+        // 128-level waves beyond 2048 columns: 2240 3 % faster, 2560 equal, 3072 7 % slower; 64-level waves gain up to
+        // 4096 columns (2560: 0.297 -> 0.214 ms, 3072: 0.360 -> 0.271, 3840: 0.510 -> 0.446, 4096: 0.560 -> 0.519)
         const bool ahead2 = ctx->opt[SMHIP_OPT_B_AHEAD] != 1;
         const bool few_cols = (long)W * n_chunks <= 2048;
         const bool ahead4 = ahead2 && few_cols && ctx->opt[SMHIP_OPT_B_AHEAD] != 2;
         const bool lred = !keep_all && !paired && b_static && window <= 11 && CH <= 128 &&
-                          (ctx->opt[SMHIP_OPT_B_LRED] < 0 ? ahead4 : ctx->opt[SMHIP_OPT_B_LRED] != 0);
+                          (ctx->opt[SMHIP_OPT_B_LRED] < 0 ? (ahead4 || (CH == 64 && (long)W * n_chunks <= 4096))
+                                                          : ctx->opt[SMHIP_OPT_B_LRED] != 0);
         const int kgrp = ((lred ? 32 : 64) / kblk) * kblk;
         // (two workgroups per CU leave each 80 KB: 36 groups, 8K x 256 5.54 -> 5.42 ms)
         int kb_groups = ctx->opt[SMHIP_OPT_KEYBUF] >= 0 ? ctx->opt[SMHIP_OPT_KEYBUF] : (b_policy && b_waves == 8 ? 36 : 18);   // 0: unbuffered
-        if (lred && ctx->opt[SMHIP_OPT_KEYBUF] < 0) kb_groups = (1134 + kgrp - 1) / kgrp;   // (the same ~9-KB runs out of shorter groups)
+        if (lred && ctx->opt[SMHIP_OPT_KEYBUF] < 0) {
+            kb_groups = (1134 + kgrp - 1) / kgrp;           // (the same ~9-KB runs out of shorter groups)
+            // with that buffer and the reduction tiles (8320 bytes per wave) two workgroups share a CU: rounds of 64 per
+            // XCD; a smaller buffer where three or four per CU fill their rounds better (as for the paired walk below)
+            const long wg_xcd = (long)((x_per_xcd + wpb - 1) / wpb) * b_chunks;
+            auto fill = [&](long per_cu) {
+                const long slots = 32 * per_cu;
+                return (double)wg_xcd / (double)((wg_xcd + slots - 1) / slots * slots);
+            };
+            int per_cu = 2;
+            if (b_policy && wg_xcd <= 128) {                // all resident at once where four per CU can hold them
+                per_cu = wg_xcd <= 64 ? 2 : wg_xcd <= 96 ? 3 : 4;
+            } else if (b_policy && fill(2) < 0.8) {
+                per_cu = fill(3) >= fill(4) - 0.05 ? 3 : 4;
+                if (fill(per_cu) <= fill(2)) per_cu = 2;
+            }
+            // (a workgroup that asks for exactly a third of the 160 KB gets a CU with one other, not two: 3 KB of margin)
+            const long room = 163840 / per_cu - 3072 - (long)wpb * 32 * 65 * (long)sizeof(int);
+            const int fit = (int)(room / ((long)wpb * kgrp * (long)sizeof(long long)));
+            if (per_cu > 2 && kb_groups > fit) kb_groups = fit > 1 ? fit : 1;
+        }
         if (kb_groups > (H + kgrp - 1) / kgrp) kb_groups = (H + kgrp - 1) / kgrp;
         if (kb_groups > 64) kb_groups = 64;                 // 4 waves x 64 groups x 64 rows x 8 B = 128 KB
         const int kb_rows = kgrp * kb_groups;
@@ -1677,7 +1700,7 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
                     per_cu = fill(3) >= fill(4) - 0.05 ? 3 : 4;
                     if (fill(per_cu) <= fill(2)) per_cu = 2;
                 }
-                const int fit = (int)((163840 / per_cu) / ((size_t)wpb * 2 * pgrp * sizeof(long long)));
+                const int fit = (int)((163840 / per_cu - 3072) / ((size_t)wpb * 2 * pgrp * sizeof(long long)));   // (3 KB of margin: an exact third gets two per CU)
                 if (per_cu > 2 && pg > fit) pg = fit;
             }
             if (pg > (H + pgrp - 1) / pgrp) pg = (H + pgrp - 1) / pgrp;
