@@ -48,7 +48,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int FUSED_F_NI = 6;                          // staged pixels per thread and chunk (at most)
 constexpr int fused_f_ni(int lpl) { return lpl == 4 ? 12 : FUSED_F_NI; }   // (a 256-level wave alone stages its row)
 
-template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false, bool W3 = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
+// STATES = true (the recomputing form of the fused path, smhip_fused_c.h): the same walk, but instead of the slab the
+// kernel writes only the running sum at the last column before every block of WIN columns -- state slot j of a row
+// holds t[WIN * j - 1], j = 1 .. ceil(W / WIN) - 1, at S[(y * nst + j) * Dp + k] (T = S, the `tyshift` argument = nst,
+// the slots per row): 4 N / WIN bytes instead of 4 N.  All levels are written (no dead elements).
+template <int WIN, bool SD, bool CUT, int DS, int LPL, int NW, int ABL = 0, int POL = 0, bool PAIRED = false, bool W3 = false, bool STATES = false>   // ABL: ablations of scripts/bench_a.hip; POL: cache policy bits of the stores
 // Waves per SIMD: the kernels of windows up to 9 need 157 VGPRs or fewer, so three waves fit a SIMD; with the
 // bound of two that this kernel had, a CU held four two-wave workgroups, the chip 1024, and config 3's 1080 rows
 // ran as one round of 1024 and a tail of 56: 0.379 ms, against 0.353 ms with all rows resident (1024 rows alone
@@ -193,10 +197,13 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     // reads a row of two columns with one 1-KiB wave load (smhip_fused_b.h, PAIR).  Step x then lies at
     // (x >> 1) * pair stride + (x & 1) * 512 bytes instead of x * xsb.
     static_assert(!PAIRED || (NW == 1 && LPL == 2), "paired layout: 128-level slabs");
-    const unsigned xsb = ((unsigned)(PAIRED ? 256 : Dp) << tyshift) * (unsigned)sizeof(float);   // bytes between consecutive x (PAIRED: pairs)
-    const int oob = (int)((unsigned)(PAIRED ? (W + 1) / 2 : W) * xsb);
+    static_assert(!STATES || !PAIRED, "states: plain level order");
+    const unsigned xsb = STATES ? (unsigned)Dp * (unsigned)sizeof(float)                           // bytes between consecutive state slots
+                                : ((unsigned)(PAIRED ? 256 : Dp) << tyshift) * (unsigned)sizeof(float);   // bytes between consecutive x (PAIRED: pairs)
+    const int oob = (int)((unsigned)(STATES ? tyshift : PAIRED ? (W + 1) / 2 : W) * xsb);
     const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-        T + (PAIRED ? slab_row_offset(y, (W + 1) / 2, 256, tyshift) : slab_row_offset(y, W, Dp, tyshift)) + kc, 0, oob,
+        T + (STATES ? (size_t)y * (size_t)tyshift * Dp
+                    : PAIRED ? slab_row_offset(y, (W + 1) / 2, 256, tyshift) : slab_row_offset(y, W, Dp, tyshift)) + kc, 0, oob,
         0x00020000);
     const int lane_off = (kbase - kc) * 4;
     unsigned tb = 0;                                   // byte offset of the current block's first step
@@ -210,7 +217,9 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                             : (unsigned)(s >> 1) * xsb + (unsigned)(s & 1) * 512u);
     };
     auto next_block = [&]() {
-        if constexpr (!PAIRED) {
+        if constexpr (STATES) {
+            tb += xsb;                                 // one slot per block
+        } else if constexpr (!PAIRED) {
             tb += WIN * xsb;
         } else {
             static_assert(!PAIRED || (WIN & 1), "odd windows");
@@ -268,7 +277,10 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
                 ring[i][s] = c;
             }
-            if (!(ABL & 1))
+            if constexpr (STATES) {
+                if (s == WIN - 2)                      // x = WIN * (b + 1) - 1: the state in front of the next block
+                    put(lane_off, tb, acc);
+            } else if (!(ABL & 1))
                 put(lane_off, soff(s), acc);
         }
         next_block();
@@ -297,7 +309,10 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
                 ring[i][s] = c;
             }
-            if (!(ABL & 1))
+            if constexpr (STATES) {
+                if (s == WIN - 2)
+                    put(lane_off, tb, acc);
+            } else if (!(ABL & 1))
                 put(lane_off + (-(int)!(keep_all || lane_live(xb + s)) & oob), soff(s), acc);   // (a ?: here became a table in scratch)
         }
         next_block();
@@ -316,7 +331,10 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                     acc[i] = acc[i] + scale * (mag(c) - mag(ring[i][s]));
                     ring[i][s] = c;
                 }
-                if (!((ABL & 1) && x + 2 < W))
+                if constexpr (STATES) {
+                    if (s == WIN - 2)
+                        put(lane_off, tb, acc);
+                } else if (!((ABL & 1) && x + 2 < W))
                     put(lane_off + (-(int)!(keep_all || lane_live(x)) & oob), soff(s), acc);
             }
         }
@@ -352,8 +370,9 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                     acc[i] += scale * mag(c);
                 }
             }
-            put(lane_off, 0, acc);
-            tb = PAIRED ? 512u : xsb;                  // tb = offset of step x = 1 + WIN * b from here on
+            if constexpr (!STATES)
+                put(lane_off, 0, acc);
+            tb = PAIRED ? 512u : xsb;                  // tb = offset of step x = 1 + WIN * b from here on (STATES: of slot b + 1)
             px = 1;
         }
 
