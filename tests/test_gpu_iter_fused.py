@@ -144,6 +144,30 @@ def test_every_other_case_takes_the_stage_calls(gpu_ctx, oracle, w, h, b, D, agg
     check(gpu_ctx, oracle, w, h, b, D, aggr_fn, n_iter, slabs=2, **kw)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SMHIP_FUZZ_ITER_N", "60"))))   # more on demand
+def test_random_shapes(gpu_ctx, oracle, seed):
+    """Random frames (several pixel tiles and row segments, widths % 4 == 0 mostly), level counts, iteration counts
+    on both sides of the one-kernel limits, directions, steps, slabs and launch shapes."""
+    r = np.random.RandomState(4100 + seed)
+    w = int(r.randint(4, 110)) * 4 if r.rand() < 0.85 else int(r.randint(9, 300))
+    h = int(r.choice([int(r.randint(3, 40)), int(r.randint(40, 200))]))
+    b = int(r.choice([1, 1, 4]))
+    D = int(r.choice([int(r.randint(2, 20)), int(r.randint(20, 100))]))
+    fn = int(r.choice([2, 3]))
+    n_iter = int(r.choice([int(r.randint(0, 5)), int(r.randint(5, 14))]))
+    step = int(r.choice([1, 1, 2, 3]))
+    sign = int(r.choice([1, -1]))
+    dmin = int(r.randint(-6, 7))
+    kw = dict(match_fn=int(r.choice([1, 2])), match_interval=int(r.rand() < 0.6), match_max=int(r.choice([1000, 30, 3])))
+    if fn == 3:
+        kw["diff_lambda"] = float(r.choice([0.15, 0.05, 0.2, 0.25]))
+    slabs = int(r.randint(1, 4)) if D >= 6 else 1
+    opts = dict(iter_groups=int(r.choice([-1, -1, 1, 2, 5])), tseg=int(r.choice([-1, -1, 16, 64])))
+    with gpu_ctx.options(**opts):
+        check(gpu_ctx, oracle, w, h, b, D, fn, n_iter, slabs=slabs, dmin=dmin, step=step, sign=sign, seed=900 + seed,
+              noise=bool(r.rand() < 0.3), **kw)
+
+
 def test_argument_errors(gpu_ctx):
     w, h, D = 64, 16, 8
     left, right, _ = synth.scene_pair(w, h, D)
