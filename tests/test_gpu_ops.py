@@ -418,6 +418,61 @@ def test_diffusion_run_pixels_on_lanes(gpu_ctx, oracle, h, w, d, n_iter):
                           "diffusion x%d" % n_iter)
 
 
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("SMHIP_FUZZ_OPS_N", "40"))))   # more on demand
+def test_random_iterated_operators(gpu_ctx, oracle, seed):
+    """The iterated stage operators and the min filter + WTA kernel on random volumes and launch shapes: every form
+    the library can be told to take (LDS tiles of 64 / 128 pixels, pixels on lanes with 16 / 32 levels per workgroup,
+    short and long row segments, any depth per pass) gives the oracle's bits."""
+    from stereomatch_amd import capi, sharding
+    r = np.random.RandomState(6100 + seed)
+    w = int(r.randint(2, 90)) * 4 if r.rand() < 0.8 else int(r.randint(5, 300))
+    h = int(r.choice([int(r.randint(2, 30)), int(r.randint(30, 180))]))
+    d = int(r.choice([4, 8, 12, 20, 36, 40, 68]))
+    n_iter = int(r.randint(1, 12))
+    opts = dict(multi_px=int(r.choice([-1, 0, 16, 32])), multi_txt=int(r.choice([-1, 64, 128])),
+                tseg=int(r.choice([-1, -1, 16, 128])), maxk=int(r.choice([-1, -1, 1, 2, 3])))
+    kind = "float" if r.rand() < 0.7 else "int"
+    c = util.rand_dsi(h, w, d, 700 + seed, kind)
+    op = int(r.choice([0, 1, 2]))
+    if op == 0:                                        # binomial 14641
+        want = c
+        for _ in range(n_iter):
+            want = oracle.convolve_14641(want)
+        with gpu_ctx.options(**opts):
+            bufs = (up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4))
+            in_b = gpu_ctx.convolve_14641_run(bufs[0], bufs[1], w, h, d, w * d, n_iter)
+        util.assert_bit_equal(gpu_ctx.download(bufs[1] if in_b else bufs[0], (h, w, d), np.float32), want,
+                              "binomial x%d %r" % (n_iter, opts))
+    elif op == 1:                                      # diffusion
+        lam = float(r.choice([0.15, 0.05, 0.25]))
+        want = c
+        for _ in range(n_iter):
+            want = oracle.diffusion_iter(want, lam, 0.0, None)
+        with gpu_ctx.options(**opts):
+            bufs = (up(gpu_ctx, c), gpu_ctx.alloc(h * w * d * 4))
+            in_b = gpu_ctx.diffusion_run(bufs[0], bufs[1], None, w, h, d, w * d, lam, 0.0, n_iter)
+        util.assert_bit_equal(gpu_ctx.download(bufs[1] if in_b else bufs[0], (h, w, d), np.float32), want,
+                              "diffusion x%d %r" % (n_iter, opts))
+    else:                                              # min filter + PadCosts + WTA keys
+        mf = int(r.choice([3, 5, 7, 9, 11]))
+        if mf > min(w, h):
+            mf = 3
+        if min(w, h) < 3:
+            return
+        sign = int(r.choice([1, -1]))
+        fr, fm = (0, 1) if sign > 0 else (1, 0)
+        po = oracle.make_params(w, h, 1, disp_max=d - 1, frame_ref=fr, frame_match=fm)
+        wd, wb = oracle.wta(oracle.pad_costs(oracle.min_filter(c, mf), po))
+        p = capi.match_params(w, h, 1, d, frame_diff_sign=sign)
+        keys = gpu_ctx.alloc(w * h * 8)
+        with gpu_ctx.options(iter_groups=int(r.choice([-1, 1, 3])), multi_txt=opts["multi_txt"],
+                             tseg=int(r.choice([-1, 8, 32, 64]))):
+            gpu_ctx.min_pad_wta_keys(up(gpu_ctx, c), w * d, p, mf, 0, d, keys)
+        gd, gb = sharding.decode_keys(gpu_ctx.download(keys, (w, h), np.int64).T)
+        assert np.array_equal(gd, wd), (seed, mf, opts)
+        util.assert_bit_equal(np.ascontiguousarray(gb), wb, "min %d + WTA best cost" % mf)
+
+
 def test_tile_kernels_with_long_row_segments(gpu_ctx, oracle, request):
     """Large volumes use 128-row segments in the LDS-tiled kernels; force that length on a small
     volume (the `tseg` option) so the segment logic of the production configuration is covered."""
