@@ -75,6 +75,13 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_f[];
     f32x2 *ml = (f32x2 *)lds_f;                        // matching interval (lo, hi) of positions M0 ..
     float *rl = (float *)(ml + nmatch);                // reference value of positions R0 ..
+    // Two levels per lane put neighbouring lanes two positions (16 bytes) apart: read as one array, a wave's
+    // ds_read_b64 hits every bank four times (16.9 M conflict cycles per launch at config 3).  SPLIT keeps the
+    // even and the odd positions in two arrays, so the lanes of one read are 8 bytes apart: conflict-free.  The
+    // parity of a lane's first position is the same in every lane of the wave.
+    constexpr bool SPLIT = LPL == 2;
+    f32x2 *mle = ml, *mlo = ml + (nmatch + 1) / 2;     // SPLIT: positions M0 + 2 i / M0 + 2 i + 1
+    auto mlat = [&](int i) -> f32x2 & { return SPLIT ? ((i & 1) ? mlo : mle)[i >> 1] : ml[i]; };
     const int W = a.W, D = a.D;
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     // workgroup index = row * chunks + chunk: the chunks of a row are dispatched together, so the halves /
@@ -160,7 +167,7 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                     hi = f_nxt[j];
                 }
                 f32x2 v = {(float)lo, (float)hi};
-                ml[i] = v;
+                mlat(i) = v;
             }
             if (i <= g.R1 - g.R0)
                 rl[i] = (float)f_ref[j];
@@ -185,7 +192,7 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
         int xm = xr + disp[i];
         bool out = (unsigned)xm >= (unsigned)W;
         int xc = (int)min((unsigned)max(xm, 0), (unsigned)(W - 1));
-        float e = dist(rl[xr - R0], ml[xc - M0]);
+        float e = dist(rl[xr - R0], mlat(xc - M0));
         return out ? outf : e;
     };
     // Slab addresses: buffer stores with a wave-uniform descriptor (this row at x = 0, first level of the
@@ -257,12 +264,31 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     float acc[LPL], ring[LPL][WIN];
     // the lane's NPX matching pixels of block b start at the lowest position it needs
     auto pos0 = [&](int b) { return 1 + WIN * b + pr + disp[0] - (DS < 0 ? LPL - 1 : 0); };
-    auto load_block = [&](f32x2 (&pm)[NPX], float (&rv)[WIN], int b) {
-        const f32x2 *mp = ml + (pos0(b) - M0);
+    // SPLIT: where the lane's positions e, e + 2, .. (pa) and e + 1, e + 3, .. (pb) of the next block to load lie;
+    // WIN is odd, so from one block to the next the two arrays change roles
+    const f32x2 *pa = mle, *pb = mlo;
+    auto aim = [&](int b) {
+        if constexpr (SPLIT) {
+            const int e = pos0(b) - M0;                // (its parity is wave-uniform)
+            pa = ((e & 1) ? mlo : mle) + (e >> 1);
+            pb = (e & 1) ? mle + ((e + 1) >> 1) : mlo + (e >> 1);
+        }
+    };
+    auto load_block = [&](f32x2 (&pm)[NPX], float (&rv)[WIN], int b) {     // blocks in sequence after aim(first block)
         const float *rp = rl + (1 + WIN * b + pr - R0);
+        if constexpr (SPLIT) {
 #pragma unroll
-        for (int j = 0; j < NPX; j++)
-            pm[j] = mp[j];
+            for (int j = 0; j < NPX; j++)
+                pm[j] = (j & 1) ? pb[j >> 1] : pa[j >> 1];
+            const f32x2 *t = pa;
+            pa = pb + (WIN - 1) / 2;
+            pb = t + (WIN + 1) / 2;
+        } else {
+            const f32x2 *mp = ml + (pos0(b) - M0);
+#pragma unroll
+            for (int j = 0; j < NPX; j++)
+                pm[j] = mp[j];
+        }
 #pragma unroll
         for (int s = 0; s < WIN; s++)
             rv[s] = rp[s];
@@ -295,7 +321,7 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
 #pragma unroll
         for (int j = 0; j < NPX; j++) {
             ok[j] = (unsigned)(p0 + j) < (unsigned)W;
-            pm[j] = ml[clampi(p0 + j, W) - M0];
+            pm[j] = mlat(clampi(p0 + j, W) - M0);
         }
 #pragma unroll
         for (int s = 0; s < WIN; s++)
@@ -382,6 +408,7 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
                 const int be = min(c1, b_int1);        // interior blocks are one interval: [b, be) here
                 f32x2 mA[NPX], mB[NPX];
                 float rA[WIN], rB[WIN];
+                aim(b);
                 load_block(mA, rA, b);
                 for (; b + 2 <= be; b += 2) {          // two blocks per trip: the ring and the LDS
                     load_block(mB, rB, b + 1);         // prefetch alternate between two register sets
