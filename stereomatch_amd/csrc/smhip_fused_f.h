@@ -77,9 +77,15 @@ void fused_rawbox_h_f_kernel(FusedA a, float *__restrict__ T, int tyshift,
     float *rl = (float *)(ml + nmatch);                // reference value of positions R0 ..
     // Two levels per lane put neighbouring lanes two positions (16 bytes) apart: read as one array, a wave's
     // ds_read_b64 hits every bank four times (16.9 M conflict cycles per launch at config 3).  SPLIT keeps the
-    // even and the odd positions in two arrays, so the lanes of one read are 8 bytes apart: conflict-free.  The
-    // parity of a lane's first position is the same in every lane of the wave.
-    constexpr bool SPLIT = LPL == 2;
+    // even and the odd positions in two arrays, so the lanes of one read are 8 bytes apart: conflict-free (0.5 M).
+    // The parity of a lane's first position is the same in every lane of the wave.  Measured (-DSMK_F_SPLIT=1,
+    // profiles/r03_pass_a_lds_split.log): the conflicts go, the time does not -- 5 % more VALU instructions and one
+    // more LDS instruction per block (two runs of five positions instead of one of ten), and pass A is no faster
+    // (traced 353.8 against 346.4 / 350.4 us); the LDS pipe is 10 % active and not what pass A waits for.  Off in the product.
+#ifndef SMK_F_SPLIT
+#define SMK_F_SPLIT 0
+#endif
+    constexpr bool SPLIT = SMK_F_SPLIT && LPL == 2;
     f32x2 *mle = ml, *mlo = ml + (nmatch + 1) / 2;     // SPLIT: positions M0 + 2 i / M0 + 2 i + 1
     auto mlat = [&](int i) -> f32x2 & { return SPLIT ? ((i & 1) ? mlo : mle)[i >> 1] : ml[i]; };
     const int W = a.W, D = a.D;
