@@ -91,6 +91,7 @@ enum smhip_option {
     SMHIP_OPT_ITER_GROUPS,    /* smhip_fused_iter_wta_keys: level groups (workgroups along the levels) of the keys kernels, 1..16 */
     SMHIP_OPT_A_NW,           /* float-lane pass A on 256-level chunks: 0 = two-wave workgroups, 1 = one-wave workgroups of 128 levels, 4 = one wave of four levels per lane (window 9) */
     SMHIP_OPT_B_LRED,         /* pass B of slabs up to 128 levels: 1 = the wave minimum of a group of rows through LDS at any width, 0 = the per-row DPP chain; default: LDS on up to 2048 columns */
+    SMHIP_OPT_ITER_DIRECT,    /* smhip_fused_iter_wta_keys: 1 = one level tile per workgroup with long row segments and a key image per tile (2..64 tiles), 0 = level tiles looped inside 64-row segments */
     SMHIP_OPT_COUNT
 };
 int smhip_set_option(smhip_ctx *ctx, int option, int value);

@@ -186,7 +186,7 @@ def _ptr(x):
 
 
 # enum smhip_option (include/smhip.h)
-OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13, "multi_txt": 14, "tap_slow": 15, "multi_px": 16, "iter_fused": 17, "iter_groups": 18, "a_nw": 19, "b_lred": 20}
+OPTIONS = {"narrow": 0, "tyshift": 1, "chunk": 2, "bt_prepass": 3, "tseg": 4, "maxk": 5, "float_a": 6, "keybuf": 7, "store_policy": 8, "paired": 9, "a_lds_kb": 10, "b_waves": 11, "stage_lds_kb": 12, "b_ahead": 13, "multi_txt": 14, "tap_slow": 15, "multi_px": 16, "iter_fused": 17, "iter_groups": 18, "a_nw": 19, "b_lred": 20, "iter_direct": 21}
 
 
 class Context:

@@ -1959,6 +1959,34 @@ static int launch_iter_keys(smhip_ctx *ctx, int op, int K, int src, int nbk, boo
     g.tiles_per_group = (n_tiles + G - 1) / G;
     G = (n_tiles + g.tiles_per_group - 1) / g.tiles_per_group;     // no empty group
     g.seglen = seg;
+    g.direct = 0;
+    unsigned gz_direct = 0;
+    // Direct mode: one level tile per workgroup and a key image per tile (merged by keys_min_kernel), the LDS key
+    // arrays a ring that is flushed every 32 rows -- so a segment can be hundreds of rows long and the pipeline's
+    // fill (2 RL + 1 row steps per segment: 81 steps for 64 rows of four binomial iterations) is paid once per
+    // segment of 128 .. 512 rows.  Costs 16 bytes per pixel and level tile of key traffic.  Measured, 3840x2160: all
+    // 512 levels binomial x4 11.6 -> 9.7 ms, x8 20.2 -> 17.9, diffusion x6 10.0 -> 8.7, x10 14.8 -> 13.8; levels
+    // 256..319 binomial x4 1.64 -> 1.50; 1920x1080x256 binomial x4 1.87 -> 1.48 (profiles/r03_iter_direct.log).
+    // The library's choice from 128 rows on; SMHIP_OPT_ITER_DIRECT 1 / 0 forces / forbids it.
+    const bool direct_ok = n_tiles >= 2 && n_tiles <= 64;
+    const bool direct = direct_ok && (ctx->opt[SMHIP_OPT_ITER_DIRECT] < 0 ? h >= 128 : ctx->opt[SMHIP_OPT_ITER_DIRECT] != 0);
+    if (direct) {
+        // segments: as long as possible while the grid still fills at least eight rounds of the chip evenly
+        int dseg = ctx->opt[SMHIP_OPT_TSEG] >= 64 ? ctx->opt[SMHIP_OPT_TSEG] : 0;
+        if (!dseg) {
+            long S = 1;
+            while ((long)gx * n_tiles * S < 8 * per_round && (h + S) / (S + 1) >= 128)
+                S++;
+            dseg = (int)((h + S - 1) / S);
+            if (dseg > 512) dseg = 512;                // (longer segments measured slower: 768 rows 4 % behind 512)
+            dseg = (dseg + 31) / 32 * 32;
+        }
+        g.direct = 1;
+        g.tiles_per_group = 1;
+        g.seglen = dseg;
+        G = n_tiles;
+        gz_direct = (unsigned)((h + dseg - 1) / dseg);
+    }
     const size_t n_pix = (size_t)w * h;
     g.part_stride = n_pix;
     g.pw.keys = (long long *)d_keys;
@@ -1970,7 +1998,7 @@ static int launch_iter_keys(smhip_ctx *ctx, int op, int K, int src, int nbk, boo
     }
     if (gz > 65535)
         return fail(SMHIP_EINVAL, "iterated fused path: more than %d rows", 65535 * seg);
-    if (!smk::launch_iter_px(op, K, src, smk::IPX_KEYS, nbk, sd, g, gx, (unsigned)G, gz, ctx->stream))
+    if (!smk::launch_iter_px(op, K, src, smk::IPX_KEYS, nbk, sd, g, gx, (unsigned)G, direct ? gz_direct : gz, ctx->stream))
         return fail(SMHIP_EINVAL, "iterated fused path: no kernel for %d iterations", K);
     if (G > 1)
         smk::keys_min_kernel<<<(unsigned)((n_pix + 255) / 256), 256, stage_lds(ctx), ctx->stream>>>(

@@ -53,6 +53,8 @@ struct IterPxArgs {
     FusedA a;                       // RAW source
     PadWtaArgs pw;                  // KEYS sink
     int tiles_per_group;            // KEYS sink: level tiles a workgroup walks
+    int direct;                     // KEYS sink, one tile per workgroup: the LDS key arrays are a ring of two chunks of 32
+                                    // rows that goes to the tile's key image chunk by chunk -- segments of any length
     size_t part_stride;             // KEYS sink: elements between the key images of the level groups (blockIdx.y)
 };
 
@@ -207,6 +209,18 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 pre[i] = PxStage<NB>::fetch_m(g.a, ro, clampi(M0 + it - PX_TXT, W));
         }
     };
+    // direct mode: rows y0 + rel0 .. + n - 1 (one chunk of the ring) -> this tile's key image, column-major runs
+    auto flush = [&](int rel0, int n) {
+        long long *keys = g.pw.keys + (size_t)blockIdx.y * g.part_stride;
+        for (int i = t; i < TXI * 32; i += NT) {
+            const int px = i >> 5, r = i & 31;
+            const int x = X0 + HL + px;
+            if (x < W && r < n) {
+                const int slot = px * IPX_KSTRIDE + ((rel0 + r) & 63);
+                keys[(size_t)x * H + y0 + rel0 + r] = make_key(kcost[slot], g.pw.d_first + (int)klev[slot]);
+            }
+        }
+    };
     auto step = [&](auto rr, auto edge, const int R) {
         constexpr int RR = decltype(rr)::value;
         const int p = PER == 5 ? (RR & 1) ^ (((R - Rlo) / 5) & 1)      // parity of R - Rlo = PER * g + RR
@@ -256,11 +270,23 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                     cand = c[e] == mm ? lev + e : cand;
                 cand = live ? cand : 0x7FFFFFFF;
                 cand = segq_allmin_u32<QP>(cand);
+                if (g.direct) {                     // (wave-uniform) the chunk before is complete: out it goes
+                    const int rel = qs - y0;
+                    if (rel >= 32 && (rel & 31) == 0)
+                        flush(rel - 32, 32);
+                }
                 if (lq == 0 && has_out) {
-                    const int idx = (lp - HL) * IPX_KSTRIDE + (qs - y0), oc = ordered_bits(mm);
-                    if (oc < kcost[idx]) {
+                    const int oc = ordered_bits(mm);
+                    if (g.direct) {
+                        const int idx = (lp - HL) * IPX_KSTRIDE + ((qs - y0) & 63);
                         kcost[idx] = oc;
                         klev[idx] = (unsigned short)cand;
+                    } else {
+                        const int idx = (lp - HL) * IPX_KSTRIDE + (qs - y0);
+                        if (oc < kcost[idx]) {
+                            kcost[idx] = oc;
+                            klev[idx] = (unsigned short)cand;
+                        }
                     }
                 }
             } else {
@@ -396,7 +422,11 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
         else
             rows(icst<0>{});
     }
-    if constexpr (KEYS) {
+    if (KEYS && g.direct) {
+        __syncthreads();
+        const int n = y1 - y0, last = ((n - 1) >> 5) << 5;          // the last chunk, complete or not
+        flush(last, n - last);
+    } else if constexpr (KEYS) {
         __syncthreads();
         const int rows = y1 - y0;
         long long *keys = g.pw.keys + (size_t)blockIdx.y * g.part_stride;

@@ -113,13 +113,23 @@ def test_slabs_merge_to_the_whole_range(gpu_ctx, oracle, slabs, n_iter):
 
 
 @pytest.mark.parametrize("opts", [{"iter_groups": 1}, {"iter_groups": 3}, {"iter_groups": 16}, {"tseg": 16}, {"tseg": 8},
-                                  {"iter_fused": 0}, {"tap_slow": 1}])
+                                  {"iter_fused": 0}, {"tap_slow": 1}, {"iter_direct": 1}, {"iter_direct": 1, "tseg": 64}])
 @pytest.mark.parametrize("n_iter", [4, 7])
 def test_launch_shapes(gpu_ctx, oracle, opts, n_iter):
     with gpu_ctx.options(**opts):
         check(gpu_ctx, oracle, 248, 90, 1, 80, 2, n_iter, match_fn=1, match_interval=1)
         check(gpu_ctx, oracle, 124, 70, 4, 20, 2, n_iter, match_fn=2, match_max=12)
         check(gpu_ctx, oracle, 248, 90, 1, 80, 3, n_iter + 3, match_fn=1, match_interval=1)
+
+
+@pytest.mark.parametrize("n_iter", [2, 4, 6, 9])
+@pytest.mark.parametrize("h,tseg", [(33, -1), (64, -1), (97, -1), (200, 64), (300, 128), (161, 96)])
+def test_direct_key_ring(gpu_ctx, oracle, h, tseg, n_iter):
+    """One level tile per workgroup, keys through the two-chunk LDS ring (iter_direct): heights around the chunks of
+    32 rows, several segments, segments that end inside a chunk."""
+    with gpu_ctx.options(iter_direct=1, tseg=tseg):
+        check(gpu_ctx, oracle, 244, h, 1, 40, 2, min(n_iter, 8), match_fn=1, match_interval=1, match_max=9)
+        check(gpu_ctx, oracle, 120, h, 4, 36, 3, n_iter, match_fn=2, slabs=2)
 
 
 @pytest.mark.parametrize("n_iter", [1, 4, 8])
@@ -162,7 +172,8 @@ def test_random_shapes(gpu_ctx, oracle, seed):
     if fn == 3:
         kw["diff_lambda"] = float(r.choice([0.15, 0.05, 0.2, 0.25]))
     slabs = int(r.randint(1, 4)) if D >= 6 else 1
-    opts = dict(iter_groups=int(r.choice([-1, -1, 1, 2, 5])), tseg=int(r.choice([-1, -1, 16, 64])))
+    opts = dict(iter_groups=int(r.choice([-1, -1, 1, 2, 5])), tseg=int(r.choice([-1, -1, 16, 64])),
+                iter_direct=int(r.choice([-1, 0, 1, 1])))
     with gpu_ctx.options(**opts):
         check(gpu_ctx, oracle, w, h, b, D, fn, n_iter, slabs=slabs, dmin=dmin, step=step, sign=sign, seed=900 + seed,
               noise=bool(r.rand() < 0.3), **kw)
