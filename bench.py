@@ -30,6 +30,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# multi-process GPU work on this pool: the host driver only supports dmabuf IPC (RCCL's buffer exchange fails with
+# hipIpcGetMemHandle otherwise); the launcher's environment normally carries it already
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 MAX_CALL_LEVELS = 256   # levels per fused call at N > 1 (bounds the slab workspace: 34 GB at 8K)
