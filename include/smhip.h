@@ -78,7 +78,7 @@ enum smhip_option {
     SMHIP_OPT_MAXK,           /* iterations per pass of the multi-iteration filters, 1..4 */
     SMHIP_OPT_FLOAT_A,        /* 0: pass A by the integer kernels also where the float-lane kernel applies */
     SMHIP_OPT_KEYBUF,         /* key groups (of ~64 rows) pass B collects in LDS before it stores them; 0: none */
-    SMHIP_OPT_STORE_POLICY,   /* cache policy of the float-lane pass A's slab stores: 0 plain, 16 sc1, 18 sc1 + nt */
+    SMHIP_OPT_STORE_POLICY,   /* cache policy of the float-lane pass A's slab stores: 0 plain, 16 sc1, 18 sc1 + nt (18 also makes pass B's key stores non-temporal, the library's choice from 16 M pixels on) */
     SMHIP_OPT_PAIRED,         /* slabs of 65..128 levels: 0 one column per wave, 1 columns in pairs at any width */
     SMHIP_OPT_A_LDS_KB,       /* least LDS per workgroup of the float-lane pass A, KiB (<= 80): bounds the workgroups per CU; 0 none */
     SMHIP_OPT_B_WAVES,        /* pass B waves resident per CU, 6..16 (even; bounded through the LDS a workgroup asks for); 0 no bound */

@@ -73,5 +73,25 @@ int main()
             RUN3(4, "8K x 128 paired: non-temporal key stores");
         }
     }
+    // one column per wave, 256 levels, large frames: plain against non-temporal key stores
+    {
+        CK(hipFree(T)); CK(hipFree(keys));
+        for (int big = 0; big < 2; big++) {
+            const int W4 = big ? 7680 : 3840, H4 = big ? 4320 : 2160, Dp4 = 256;
+            CK(hipMalloc(&T, (size_t)W4 * Dp4 * (H4 + 32) * 4)); CK(hipMalloc(&keys, (size_t)W4 * H4 * 8));
+            CK(hipMemset(T, 0, (size_t)W4 * Dp4 * (H4 + 32) * 4));
+            double B4 = (double)W4 * H4 * Dp4 * 4;
+            const int xp4 = (W4 + 7) / 8, kb = 63 * 36;
+#define RUN4(ABL, NAME) timeit(NAME, B4, [&] { dim3 g(8 * ((xp4 + 3) / 4), 1); \
+    smk::fused_boxv_wta_vpl_kernel<9, 4, ABL><<<g, 256, 81920>>>(T, tyshift, W4, H4, Dp4, Dp4, 9, scale, 0, -1, 1000.f, 0, xp4, keys, (size_t)W4 * H4, nullptr, 0, kb); })
+            for (int rep = 0; rep < 2; rep++) {
+                RUN4(0, big ? "8K x 256: plain key stores" : "4K x 256: plain key stores");
+                RUN4(4, big ? "8K x 256: non-temporal key stores" : "4K x 256: non-temporal key stores");
+                RUN4(2, big ? "8K x 256: no key stores" : "4K x 256: no key stores");
+            }
+            CK(hipFree(T)); CK(hipFree(keys));
+        }
+        T = nullptr; keys = nullptr;
+    }
     return 0;
 }

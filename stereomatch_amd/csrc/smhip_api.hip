@@ -1501,7 +1501,10 @@ static int fused_impl(smhip_ctx *ctx, const uint8_t *d_ref, const uint8_t *d_mtc
         if (rc) return rc;
         kout = (long long *)part;
     }
-    const int merge_b = merge_in_b ? 1 : 0;
+    // (bit 1: non-temporal key stores in pass B, frames of 16 M pixels and more -- smhip_fused_b.h)
+    //  SMHIP_OPT_STORE_POLICY = 18, the large-slab policy of pass A, forces them as well: tests)
+    const int merge_b = (merge_in_b ? 1 : 0) |
+                        ((n_pix >= ((size_t)16 << 20) || ctx->opt[SMHIP_OPT_STORE_POLICY] == 18) ? 2 : 0);
     smk::RawArgs a;
     rc = prepare_raw(ctx, d_ref, d_mtc, img_pitch, p, d_first, d_count, &a, bt_inline);
     if (rc) return rc;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
     int disp0, int dstep, float outside, int d_first, int x_per_xcd,
     long long *__restrict__ keys, size_t keys_chunk_stride, float *__restrict__ S = nullptr,
     size_t s_row_elems = 0, int kb_rows = 0,          // kb_rows: a multiple of GRP; dynamic LDS = waves * kb_rows * 8 (PAIR: * 16)
-    int merge = 0)                                     // 1: keys[] holds the keys of other levels; store the minimum
+    int merge = 0)                                     // bit 0: keys[] holds the keys of other levels, store the minimum; bit 1: non-temporal key stores
 {
     static_assert(!PAIR || (VPL == 4 && !STORE), "paired columns: four levels per lane, keys out");
     static_assert(!LRED || (VPL <= 2 && !STORE && !PAIR), "row groups reduced through LDS: one or two levels per lane, keys out");
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
             if (kb_rows == 0) {                         // unbuffered (no dynamic LDS given)
                 if (klane < GRP && g0 + klane < H && col) {
                     long long v = make_key(key_hi, key_lo);
-                    if (merge) {
+                    if (merge & 1) {
                         const long long o = kout[g0 + klane];
                         v = o < v ? o : v;
                     }
@@ -296,12 +296,15 @@ __global__ __launch_bounds__(256) void fused_boxv_wta_vpl_kernel(
                 kbuf[g0 - kb_first + klane] = make_key(key_hi, key_lo);
             if (g0 + GRP - kb_first == kb_rows || last) {
                 const int n = col ? min(kb_rows, H - kb_first) : 0;
-                if (merge) {                            // (the old keys are read in the same long runs the new ones are written in)
+                if (merge & 1) {                        // (the old keys are read in the same long runs the new ones are written in)
                     for (int i = klane; i < n; i += KLANES) {
                         const long long o = kout[kb_first + i], v = kbuf[i];
-                        kout[kb_first + i] = o < v ? o : v;
+                        if (merge & 2)
+                            __builtin_nontemporal_store(o < v ? o : v, kout + kb_first + i);
+                        else
+                            kout[kb_first + i] = o < v ? o : v;
                     }
-                } else if (PAIR || (ABL & 4)) {         // non-temporal key stores: 7680x4320x128 2.78 -> 2.68 ms (one column per wave, 1920x1080x256: 0.309 either way)
+                } else if (PAIR || (merge & 2) || (ABL & 4)) {   // non-temporal key stores: 7680x4320x128 (paired) 2.78 -> 2.68 ms, 7680x4320x256 5.40 -> 5.29; 3840x2160x256 and 1920x1080x256 the same either way, so one column per wave takes them from 16 M pixels on (merge bit 1)
                     for (int i = klane; i < n; i += KLANES)
                         __builtin_nontemporal_store(kbuf[i], kout + kb_first + i);
                 } else {

@@ -104,6 +104,8 @@ def test_disparity_slabs_merge_to_full_result(gpu_ctx, oracle, D, slabs):
     (151, 64, 1, 256, 9, 2, {"paired": 1}),     # 128-level calls, columns in pairs
     (96, 40, 4, 40, 7, 4, {}),                  # 10-level calls of a 4-band pair
     (120, 50, 1, 1024, 9, 2, {}),               # 512-level calls: two chunks each + the old keys
+    (150, 130, 1, 512, 9, 2, {"store_policy": 18}),     # the large-frame policy: non-temporal slab and key stores
+    (150, 130, 1, 256, 9, 2, {"store_policy": 18, "b_lred": 0}),
 ])
 def test_keys_merge_entry_point(gpu_ctx, oracle, w, h, b, D, win, calls, opts):
     """smhip_fused_box_wta_keys_merge: a level range walked in several calls, each folding its keys into the
