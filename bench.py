@@ -440,9 +440,9 @@ def extra_configs(np, capi, synth, ctx):
         d_ref, d_mtc = ctx.upload(left), ctx.upload(right)
         a, b = ctx.alloc(N * 4), ctx.alloc(N * 4)
         ctx.raw_costs(d_ref, d_mtc, W, p, a, W * D)
-        # kernels of the _run calls at this shape: the binomial in 128-pixel LDS tiles, up to 4 iterations per pass;
-        # the diffusion in the pixels-on-lanes form, up to 6 per pass (smhip_api.hip)
-        bk, dk = "smk::binomial_multi_kernel<%d, 128>", "smk::iter_px_kernel<1, %d, 32, 0, 0, false, 2>"
+        # kernels of the _run calls at this shape: both in the pixels-on-lanes form, the binomial up to 4 iterations
+        # per pass, the diffusion up to 6 (smhip_api.hip)
+        bk, dk = "smk::iter_px_kernel<0, %d, 32, 0, 0, false, 2>", "smk::iter_px_kernel<1, %d, 32, 0, 0, false, 2>"
         for name, iters, kfmt, maxk, fn in (
                 ("binomial_x4", 4, bk, 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 4)),
                 ("binomial_x8", 8, bk, 4, lambda: ctx.convolve_14641_run(a, b, W, H, D, W * D, 8)),

@@ -86,7 +86,7 @@ enum smhip_option {
     SMHIP_OPT_B_AHEAD,        /* pass B of slabs up to 128 levels: 1 = one block of rows in flight, 2 = two; default two, four on up to 2048 columns */
     SMHIP_OPT_MULTI_TXT,      /* pixels per tile of the multi-iteration binomial pass, halo included: 64 or 128 (default: 128 from 1 GiB on) */
     SMHIP_OPT_TAP_SLOW,       /* 1: the binomial passes always take the plain ten-operation tap sum (tests) */
-    SMHIP_OPT_MULTI_PX,       /* pixels-on-lanes kernels in the _run calls (width % 4 == 0): binomial 16 / 32 = levels per workgroup, default off; diffusion > 0 = always, default from 64 MiB on; 0 = never */
+    SMHIP_OPT_MULTI_PX,       /* pixels-on-lanes kernels in the _run calls (width % 4 == 0): binomial default on, 0 = the LDS-tiled form; diffusion > 0 = always, default from 64 MiB on, 0 = never */
     SMHIP_OPT_ITER_FUSED,     /* smhip_fused_iter_wta_keys: 0 = always the stage calls on a private DSI (tests) */
     SMHIP_OPT_ITER_GROUPS,    /* smhip_fused_iter_wta_keys: level groups (workgroups along the levels) of the keys kernels, 1..16 */
     SMHIP_OPT_A_NW,           /* float-lane pass A on 256-level chunks: 0 = two-wave workgroups, 1 = one-wave workgroups of 128 levels, 4 = one wave of four levels per lane (window 9) */

@@ -939,7 +939,10 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
             // Tile shape (3840x2160x512, K = 4, scripts/bench_binom.py -> profiles/r03_binom_variants.log): 64 pixels x
             // 128 rows 10.7 ms, 128 pixels (1024 threads, one workgroup per CU) 9.6, with 256-row segments 9.2 --
             // the halo's share of the arithmetic falls from 1.50 to 1.21.  Small volumes keep the 64-pixel tile
-            // (more, smaller workgroups).  The pixels-on-lanes kernel (smhip_multi_px.h) is 9.5 ms here: an option.
+            // (more, smaller workgroups).  Since the pixels-on-lanes kernel keeps its pixels in the order (0, 2, 1, 3)
+            // (smhip_iter_px.h) it beats the LDS form at every size measured -- 3840x2160x512 x4 9.4 -> 8.2 ms, x8 19.3 ->
+            // 16.9, 1920x1080x256 1.73 -> 1.41, x64 0.55 -> 0.40, 640x480x64 0.120 -> 0.109 -- and is the library's choice
+            // for widths that are a multiple of 4; SMHIP_OPT_MULTI_PX = 0 keeps the LDS form.
             const size_t vol = row_elems * (size_t)h * sizeof(float);
             const bool big = vol >= ((size_t)1 << 30) && w >= 1024;
             const int txt = ctx->opt[SMHIP_OPT_MULTI_TXT] > 0 ? ctx->opt[SMHIP_OPT_MULTI_TXT] : (big ? 128 : 64);
@@ -949,25 +952,14 @@ int smhip_convolve_14641_run(smhip_ctx *ctx, float *d_a, float *d_b, int w, int 
             if (big && ctx->opt[SMHIP_OPT_TSEG] < 0 && h >= 512)
                 tseg = 256;
             const unsigned gz = (h + tseg - 1) / tseg;
-            if (w % 4 == 0 && pxo > 0) {        // pixels on lanes (smhip_multi_px.h)
-                const int lv = pxo == 16 ? 16 : 32;
-                dim3 grid((w + smk::px_txi(K) - 1) / smk::px_txi(K), (nb + lv - 1) / lv, gz);
-#define LAUNCH_PX(KK, LL) smk::binomial_px_kernel<KK, LL><<<grid, LL * 32, stage_lds(ctx), ctx->stream>>>( \
-                    cur, oth, w, nb, h, row_elems, tseg, slow)
-                if (lv == 32) {
-                    switch (K) {
-                    case 2: LAUNCH_PX(2, 32); break;
-                    case 3: LAUNCH_PX(3, 32); break;
-                    default: LAUNCH_PX(4, 32); break;
-                    }
-                } else {
-                    switch (K) {
-                    case 2: LAUNCH_PX(2, 16); break;
-                    case 3: LAUNCH_PX(3, 16); break;
-                    default: LAUNCH_PX(4, 16); break;
-                    }
-                }
-#undef LAUNCH_PX
+            if (w % 4 == 0 && pxo != 0) {       // pixels on lanes (smhip_iter_px.h, resident DSI in and out)
+                smk::IterPxArgs g;
+                memset(&g, 0, sizeof(g));
+                g.W = w; g.H = h; g.D = nb; g.row_elems = row_elems;
+                g.force_slow = slow;
+                g.src = cur; g.dst = oth;
+                rc = launch_iter_dsi(ctx, smk::IPX_BINOMIAL, K, smk::IPX_DSI, 2, false, g);
+                if (rc) return rc;
                 left -= K;
                 float *t = cur; cur = oth; oth = t;
                 *result_in_b ^= 1;

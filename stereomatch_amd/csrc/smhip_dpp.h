@@ -21,4 +21,14 @@ __device__ __forceinline__ float lane_from_below(float v, float edge)
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), DPP_WAVE_SHR1,
                                                       0xF, 0xF, false));
 }
+// The same moves for callers whose lane 63 / lane 0 is a halo lane that may receive anything (here: 0, bound_ctrl):
+// no fallback register has to be loaded in front of the move.
+__device__ __forceinline__ float lane_from_above_any(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_WAVE_SHL1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float lane_from_below_any(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), DPP_WAVE_SHR1, 0xF, 0xF, true));
+}
 }  // namespace smk

@@ -146,6 +146,12 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
     const bool left_edge = xb == 0, right_edge = xb + 3 == W - 1;
     // DSI layout: pixel lp of the tile, levels 4 lq .. + 3 of the tile
     const int lp = t / QP, lq = t % QP;
+    // A compute thread keeps its four pixels in the order (0, 2, 1, 3): with packed f32 instructions working on aligned
+    // register pairs, the pairs (px0, px2) and (px1, px3) make every operand pair of the horizontal taps either one of
+    // the two pairs themselves or one of them shifted by a whole pixel pair -- four register moves per level instead of
+    // nine, and no tap left unpaired (204 -> 17x instructions per row step at four binomial iterations).  The LDS
+    // transposes do the permutation: column lpc holds pixel lp.
+    const int lpc = (lp & ~3) | ((lp & 1) << 1) | ((lp >> 1) & 1);
     const bool has_out = lp >= HL && lp < PX_TXT - HL && X0 + lp < W;
     // RAW: staged words
     const int adstep = g.a.dstep < 0 ? -g.a.dstep : g.a.dstep;
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
     int k0 = 0;                     // first level of the tile
     size_t lcol = 0;                // DSI source / sink: this thread's column
     bool lact = false;              // DSI layout: its four levels exist
-    bool padded[4] = {false, false, false, false}, dead[4] = {false, false, false, false};
+    bool repl[4] = {false, false, false, false};       // KEYS: the level's cost is replaced (PadCosts, beyond the slab, no output pixel)
+    float replv[4] = {0.0f, 0.0f, 0.0f, 0.0f};         // ... by this
     int dl = 0, mslot = 0, M0 = 0;  // RAW: this thread's disparity, its first matching slot, first staged matching pixel
     vec ring[K][PER];               // binomial: level j's horizontally filtered rows n-4 .. n, slot = row mod 5;
                                     // diffusion: level j's rows n-2 .. n, slot = row mod 3
@@ -179,23 +186,29 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
         return vtap5_pow2<4>(s0, s1, s2, s3, s4);
     };
     auto htap = [&](vec v, auto fast, auto edge) -> vec {
-        float l2 = lane_from_below(v[2], v[0]), l3 = lane_from_below(v[3], v[0]);
-        float r0 = lane_from_above(v[0], v[3]), r1 = lane_from_above(v[1], v[3]);
+        // v = (px0, px2, px1, px3); pixels 2, 3 of the lane below and 0, 1 of the lane above
+        // (lanes 0 and 63, like the first and last lane of every level, hold halo pixels: what they receive is never used)
+        float l2 = lane_from_below_any(v[1]), l3 = lane_from_below_any(v[3]);
+        float r0 = lane_from_above_any(v[0]), r1 = lane_from_above_any(v[2]);
         if constexpr (decltype(edge)::value) {   // (only tiles that hold pixel 0 or W-1 pay for the selects)
             if (left_edge)
                 l2 = l3 = v[0];
             if (right_edge)
                 r0 = r1 = v[3];
         }
-        const float w[8] = {l2, l3, v[0], v[1], v[2], v[3], r0, r1};
-        vec h;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            if (RAW || decltype(fast)::value || !slow)
-                h[e] = tap5_pow2(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
-            else
-                h[e] = tap5(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
+        // outputs (h0, h2) take the operand pairs (w[j], w[j + 2]), outputs (h1, h3) the pairs (w[j + 1], w[j + 3]) of
+        // w = l2 l3 px0 px1 px2 px3 r0 r1: five pairs each, two of them v's own register pairs
+        typedef typename fvec<2>::type f2;
+        const f2 pa = {l2, v[0]}, pb = {l3, v[2]}, p0 = {v[0], v[1]}, p1 = {v[2], v[3]}, pc = {v[1], r0}, pd = {v[3], r1};
+        f2 h02, h13;
+        if (RAW || decltype(fast)::value || !slow) {
+            h02 = vtap5_pow2<2>(pa, pb, p0, p1, pc);
+            h13 = vtap5_pow2<2>(pb, p0, p1, pc, pd);
+        } else {
+            h02 = vtap5<2>(pa, pb, p0, p1, pc);
+            h13 = vtap5<2>(pb, p0, p1, pc, pd);
         }
+        const vec h = {h02[0], h02[1], h13[0], h13[1]};
         return h;
     };
     auto fetch_row = [&](int R) {   // RAW: words of row R into registers
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 guard = 1;
 #pragma unroll
             for (int e = 0; e < 4; e++)
-                tin[p][4 * lq + e][lp] = nxt[e];
+                tin[p][4 * lq + e][lpc] = nxt[e];
             if (lact && R + 1 <= Rin && R + 1 >= 0 && R + 1 < H)
                 nxt = vload<4>(g.src + (size_t)(R + 1) * g.row_elems + lcol);
         }
@@ -255,20 +268,15 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 // PadCosts, then the lowest cost of the pixel's LV levels and the lowest level holding it
                 float c[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    c[e] = padded[e] ? g.pw.outside : tout[p][4 * lq + e][lp];
-                    c[e] = dead[e] ? __builtin_inff() : c[e];       // levels beyond the slab
-                }
-                float bc = fmin_hw(fmin_hw(c[0], c[1]), fmin_hw(c[2], c[3]));
-                const bool live = has_out && lact;
-                bc = live ? bc : __builtin_inff();
+                for (int e = 0; e < 4; e++)
+                    c[e] = repl[e] ? replv[e] : tout[p][4 * lq + e][lpc];   // (threads without an output pixel: +inf, never stored)
+                const float bc = fmin_hw(fmin_hw(c[0], c[1]), fmin_hw(c[2], c[3]));
                 const float mm = segq_allmin_f32<QP>(bc);
                 const int lev = k0 + 4 * lq;
                 int cand = 0x7FFFFFFF;
 #pragma unroll
                 for (int e = 3; e >= 0; e--)
                     cand = c[e] == mm ? lev + e : cand;
-                cand = live ? cand : 0x7FFFFFFF;
                 cand = segq_allmin_u32<QP>(cand);
                 if (g.direct) {                     // (wave-uniform) the chunk before is complete: out it goes
                     const int rel = qs - y0;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                     vec o;
 #pragma unroll
                     for (int e = 0; e < 4; e++)
-                        o[e] = tout[p][4 * lq + e][lp];
+                        o[e] = tout[p][4 * lq + e][lpc];
                     vstore<4>(g.dst + (size_t)qs * g.row_elems + lcol, o);
                 }
             }
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int c = min(PxStage<NB>::template gap<SD>(sr[p][4 * q4 + e], sm[p][mslot + e]), g.a.cutoff);
-                val[e] = (unsigned)(xb + e + dl) >= (unsigned)W ? (float)g.a.outside : (float)c;
+                val[(e & 2) >> 1 | (e & 1) << 1] = (unsigned)(xb + e + dl) >= (unsigned)W ? (float)g.a.outside : (float)c;   // pixel e -> its slot
             }
         } else {
             val = *(const vec *)&tin[p][l][4 * q4];
@@ -347,15 +355,16 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                     const int n = R - j;
                     const int s = (RR + 3 * K - j) % 3;         // slot of row n; n-1 in s+2, n-2 in s+1 (mod 3)
                     ring[j][s] = val;
-                    const vec c = ring[j][(s + 2) % 3];
-                    float lf = lane_from_below(c[3], c[0]), rt = lane_from_above(c[0], c[3]);
+                    const vec c = ring[j][(s + 2) % 3];   // (px0, px2, px1, px3)
+                    float lf = lane_from_below_any(c[3]), rt = lane_from_above_any(c[0]);
                     if constexpr (decltype(edge)::value) {
                         if (left_edge)
                             lf = c[0];
                         if (right_edge)
                             rt = c[3];
                     }
-                    const vec lv = {lf, c[0], c[1], c[2]}, rv = {c[1], c[2], c[3], rt};
+                    // left / right neighbours of (px0, px2, px1, px3): the second pair of lv and the first of rv are c's own
+                    const vec lv = {lf, c[2], c[0], c[1]}, rv = {c[2], c[3], c[1], rt};
                     vec u = ring[j][(s + 1) % 3], d = val;
                     if constexpr (!decltype(interior)::value) {
                         u = (n - 1 > 0) ? u : c;
@@ -382,8 +391,10 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
         if constexpr (KEYS) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                padded[e] = (unsigned)(X0 + lp + g.pw.disp0 + (k0 + 4 * lq + e) * g.pw.dstep) >= (unsigned)W;
-                dead[e] = k0 + 4 * lq + e >= D;
+                const bool padded = (unsigned)(X0 + lp + g.pw.disp0 + (k0 + 4 * lq + e) * g.pw.dstep) >= (unsigned)W;
+                const bool dead = k0 + 4 * lq + e >= D || !has_out;     // beyond the slab, or a halo pixel
+                repl[e] = padded || dead;
+                replv[e] = dead ? __builtin_inff() : g.pw.outside;
             }
         }
         if constexpr (RAW) {

@@ -62,7 +62,7 @@ bool launch_op(int K, int src, int sink, int nb, bool sd, const IterPxArgs &g, d
         return launch_s<OP, 32, IPX_RAW, IPX_DSI>(K, nb, sd, g, grid, lds, stream);
     if (src == IPX_DSI && sink == IPX_KEYS)
         return launch_s<OP, 32, IPX_DSI, IPX_KEYS>(K, nb, sd, g, grid, lds, stream);
-    if (src == IPX_DSI && sink == IPX_DSI && OP == IPX_DIFFUSION)      // (binomial: binomial_multi_kernel / binomial_px_kernel)
+    if (src == IPX_DSI && sink == IPX_DSI)
         return launch_s<OP, 32, IPX_DSI, IPX_DSI>(K, nb, sd, g, grid, lds, stream);
     return false;
 }
