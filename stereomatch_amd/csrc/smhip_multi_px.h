@@ -1,5 +1,6 @@
-// smhip_multi_px.h -- K iterations of the separable binomial 14641 (Convolve.cpp:86-254, ConvolveSeparable called
-// once per aggr_iter at StcAggregate.cpp:280-289) in one pass, "pixels on lanes".
+// smhip_multi_px.h -- the "pixels on lanes" layout of the iterated stencils (K iterations of the separable binomial
+// 14641, Convolve.cpp:86-254, or of the diffusion, in one pass): its constants.  The kernels are
+// in smhip_iter_px.h.
 //
 // The kernels of smhip_multi.h keep the DSI's own layout in registers (a thread = 4 levels of one pixel) and fetch
 // the horizontal neighbours of every level and row through LDS: 1 write + 4 reads of 16 bytes per thread, level
@@ -30,137 +31,8 @@ constexpr int PX_STRIDE = 132;      // floats per level row of the transpose buf
 constexpr int px_halo(int K) { return (2 * K + 3) / 4 * 4; }
 constexpr int px_txi(int K) { return PX_TXT - 2 * px_halo(K); }
 
-__device__ __forceinline__ float tap5_pow2(float s0, float s1, float s2, float s3, float s4)
-{
-    float acc = 0.0625f * s0;
-    acc = __builtin_fmaf(0.25f, s1, acc);
-    acc += 0.375f * s2;
-    acc = __builtin_fmaf(0.25f, s3, acc);
-    acc = __builtin_fmaf(0.0625f, s4, acc);
-    return acc;
-}
-
-template <int K, int LV>
-__global__ __launch_bounds__(LV * 32) void binomial_px_kernel(const float *__restrict__ src,
-                                                              float *__restrict__ dst, int W, int D, int H,
-                                                              size_t row_elems, int seglen, int force_slow)
-{
-    typedef typename fvec<4>::type vec;
-    constexpr int HL = px_halo(K), TXI = px_txi(K), QP = LV / 4;
-    __shared__ __attribute__((aligned(16))) float tin[2][LV][PX_STRIDE];
-    __shared__ __attribute__((aligned(16))) float tout[2][LV][PX_STRIDE];
-    __shared__ int guard;
-    const int t = threadIdx.x;
-    const int X0 = (int)blockIdx.x * TXI - HL, k0 = (int)blockIdx.y * LV;
-    const int y0 = (int)blockIdx.z * seglen, y1 = min(H, y0 + seglen);
-    // compute layout: level l of the tile, pixels X0 + 4 g .. + 3
-    const int l = t >> 5, g = t & 31;
-    const int xb = X0 + 4 * g;
-    const bool left_edge = xb == 0, right_edge = xb + 3 == W - 1;
-    // DSI layout: pixel lp of the tile, levels k0 + 4 lq .. + 3
-    const int lp = t / QP, lq = t % QP;
-    const bool lact = k0 + 4 * lq < D;
-    const size_t lcol = (size_t)clampi(X0 + lp, W) * D + (size_t)min(k0 + 4 * lq, D - 4);
-    const bool writer = lact && lp >= HL && lp < PX_TXT - HL && X0 + lp < W;
-    if (t == 0)
-        guard = force_slow;
-    const vec zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    vec ring[K][5];                             // level j: horizontally filtered rows n-4 .. n, slot = row mod 5
-#pragma unroll
-    for (int j = 0; j < K; j++)
-#pragma unroll
-        for (int i = 0; i < 5; i++)
-            ring[j][i] = zero;
-    // step R takes input row R and finishes output row R - 2 K, which leaves through LDS at step R + 1
-    const int Rlo = y0 - 2 * K, Rin = y1 - 1 + 2 * K, Rhi = Rin + 1;
-    vec nxt = zero, res = zero;
-    if (lact && Rlo >= 0 && Rlo < H)
-        nxt = vload<4>(src + (size_t)Rlo * row_elems + lcol);
-    bool slow = false;
-    __syncthreads();
-    auto tap = [&](vec s0, vec s1, vec s2, vec s3, vec s4) -> vec {
-        if (slow)
-            return vtap5<4>(s0, s1, s2, s3, s4);
-        return vtap5_pow2<4>(s0, s1, s2, s3, s4);
-    };
-    // horizontal tap sums of the thread's four pixels; FAST: no run-time choice of the arithmetic
-    auto htap = [&](vec v, auto fast) -> vec {
-        float l2 = lane_from_below(v[2], v[0]), l3 = lane_from_below(v[3], v[0]);
-        float r0 = lane_from_above(v[0], v[3]), r1 = lane_from_above(v[1], v[3]);
-        if (left_edge)
-            l2 = l3 = v[0];
-        if (right_edge)
-            r0 = r1 = v[3];
-        // scalar tap sums: the four windows overlap by one register each, which packed instructions (aligned
-        // register pairs) could only take after moving the operands
-        const float w[8] = {l2, l3, v[0], v[1], v[2], v[3], r0, r1};
-        vec h;
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            if (decltype(fast)::value || !slow)
-                h[e] = tap5_pow2(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
-            else
-                h[e] = tap5(w[e], w[e + 1], w[e + 2], w[e + 3], w[e + 4]);
-        }
-        return h;
-    };
-    auto step = [&](auto rr, const int R) {
-        constexpr int RR = decltype(rr)::value;
-        const int p = (RR & 1) ^ (((R - Rlo) / 5) & 1);     // parity of R - Rlo
-        if (!slow && tap_guard_bad(nxt))
-            guard = 1;
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-            tin[p][4 * lq + e][lp] = nxt[e];
-        if (lact && R + 1 <= Rin && R + 1 >= 0 && R + 1 < H)
-            nxt = vload<4>(src + (size_t)(R + 1) * row_elems + lcol);
-        *(vec *)&tout[p][l][4 * g] = res;       // the row finished at the step before
-        __syncthreads();
-        if (!slow)                              // the guard of this row's inputs was set before the barrier
-            slow = __builtin_amdgcn_readfirstlane(guard) != 0;
-        const int qs = R - 1 - 2 * K;           // row in tout
-        if (writer && qs >= y0 && qs < y1) {
-            vec o;
-#pragma unroll
-            for (int e = 0; e < 4; e++)
-                o[e] = tout[p][4 * lq + e][lp];
-            vstore<4>(dst + (size_t)qs * row_elems + lcol, o);
-        }
-        vec val = *(const vec *)&tin[p][l][4 * g];          // level 0, row R
-        if (!slow && R - 2 * (K - 1) >= 1 && R <= H - 1) {
-            // every level's row lies inside the image and the exact-product taps apply: one basic block
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-                const int s = (RR + 10 * K - 2 * j) % 5;
-                ring[j][s] = htap(val, icst<1>{});
-                val = vtap5_pow2<4>(ring[j][(s + 1) % 5], ring[j][(s + 2) % 5], ring[j][(s + 3) % 5],
-                                    ring[j][(s + 4) % 5], ring[j][s]);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-                const int n = R - 2 * j;        // row of level j arriving now
-                const int s = (RR + 10 * K - 2 * j) % 5;    // its ring slot; rows n-4 .. n-1 sit in s+1 .. s+4 (mod 5)
-                if (n <= H - 1) {               // rows below the image replicate the last row
-                    ring[j][s] = htap(val, icst<0>{});
-                    if (n == 0)                 // rows above the image replicate row 0
-                        ring[j][(s + 3) % 5] = ring[j][(s + 4) % 5] = ring[j][s];
-                } else {
-                    ring[j][s] = ring[j][(s + 4) % 5];
-                }
-                val = tap(ring[j][(s + 1) % 5], ring[j][(s + 2) % 5], ring[j][(s + 3) % 5], ring[j][(s + 4) % 5],
-                          ring[j][s]);          // level j+1, row n-2
-            }
-        }
-        res = val;                              // output row R - 2 K
-    };
-    for (int Rb = Rlo; Rb <= Rhi; Rb += 5) {
-        step(icst<0>{}, Rb);
-        if (Rb + 1 <= Rhi) step(icst<1>{}, Rb + 1);
-        if (Rb + 2 <= Rhi) step(icst<2>{}, Rb + 2);
-        if (Rb + 3 <= Rhi) step(icst<3>{}, Rb + 3);
-        if (Rb + 4 <= Rhi) step(icst<4>{}, Rb + 4);
-    }
-}
+// (The DSI -> DSI kernel that introduced this layout, binomial_px_kernel, is gone: iter_px_kernel<IPX_BINOMIAL, K, 32,
+// IPX_DSI, IPX_DSI> of smhip_iter_px.h is the same walk with the pixel order (0, 2, 1, 3) inside a thread and serves
+// smhip_convolve_14641_run.)
 
 }  // namespace smk
