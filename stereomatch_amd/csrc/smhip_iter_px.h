@@ -313,7 +313,10 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const int c = min(PxStage<NB>::template gap<SD>(sr[p][4 * q4 + e], sm[p][mslot + e]), g.a.cutoff);
-                val[(e & 2) >> 1 | (e & 1) << 1] = (unsigned)(xb + e + dl) >= (unsigned)W ? (float)g.a.outside : (float)c;   // pixel e -> its slot
+                if constexpr (decltype(edge)::value)    // (interior tiles: every matching position of the tile's levels is inside the row)
+                    val[(e & 2) >> 1 | (e & 1) << 1] = (unsigned)(xb + e + dl) >= (unsigned)W ? (float)g.a.outside : (float)c;   // pixel e -> its slot
+                else
+                    val[(e & 2) >> 1 | (e & 1) << 1] = (float)c;
             }
         } else {
             val = *(const vec *)&tin[p][l][4 * q4];
@@ -428,7 +431,8 @@ __global__ __launch_bounds__(LV * 32) __attribute__((amdgpu_waves_per_eu(4))) vo
                 }
             }
         };
-        if (X0 <= 0 || X0 + PX_TXT >= W)    // the tile holds an end of the image row (wave-uniform)
+        // the tile holds an end of the image row, or (raw costs) a level of the tile matches beyond one (wave-uniform)
+        if (X0 <= 0 || X0 + PX_TXT >= W || (RAW && (M0 < 0 || M0 + NM > W)))
             rows(icst<1>{});
         else
             rows(icst<0>{});
